@@ -1,0 +1,672 @@
+/*
+ * vpp_oracle.c -- CPU ORACLE for the TensorStream Video Post Processing path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * `cpu_baseline` leg and __graft_entry__.smoke() may load it, and only as the
+ * checker.  The product path (tensor-stream_amd/csrc) never links or calls it.
+ *
+ * It restates, in plain IEEE-754 C (build with -ffp-contract=off, no fast-math),
+ * the algorithm of the reference's three CUDA stages and the stage-selection
+ * logic that glues them, keeping the reference's uint8 NV12 intermediates:
+ *
+ *   stage selection        reference src/VideoProcessor.cpp:94-151
+ *   crop                   reference src/Crop.cu:4-21, 23-48
+ *   resize (5 kernels)     reference src/Resize.cu:5-91, 160-357, 359-386, 408-463
+ *   colour conversion      reference src/ColorConversion.cu:6-93, 280-330
+ *   other FourCC outputs   reference src/ColorConversion.cu:95-278, 331-373
+ *
+ * Parity status: PINNED for the colour conversion (RGB24/BGR24/Y800/UYVY/YUV444/
+ * HSV/NV12) against the reference's own fp32 golden files
+ * (tests/resources/test_references/FOURCC_320x240.yuv; see tests/golden/).
+ * NEAREST and crop are integer index math.  BILINEAR/BICUBIC/AREA at
+ * non-dyadic weights are "parity unpinned" in this container (the only goldens
+ * are CRCs of a decoded H.264 frame and no decoder exists here); they are
+ * exact by construction at every BASELINE.json ratio.
+ *
+ * Arithmetic conventions (see DESIGN.md "Arithmetic contract"):
+ *   - every float expression is evaluated operation by operation, rounded to
+ *     the type the reference source text gives it, NO fused multiply-add;
+ *   - float->int is truncation toward zero, round() is half-away-from-zero;
+ *   - pow(w,2), pow(w,3) in the bicubic stage are the correctly rounded w*w and (w*w)*w
+ *     (see cubic_coeffs; libm pow() selectable for comparison).
+ *
+ * Deviations from the reference (its behaviour there is undefined / a bug):
+ *   - reads outside the source planes return 0 instead of undefined memory
+ *     (only reachable by the YUV444 horizontal filter's last pixel, reference
+ *     src/ColorConversion.cu:131-138, and by odd sizes);
+ *   - the colour stage always covers the whole output (the reference sizes its
+ *     grid from a possibly stale dst->height, src/ColorConversion.cu:294);
+ *   - generateResizePattern is capped at ORC_MAX_PATTERN rows;
+ *   - the colour stage indexes the UV plane with pitch_uv (the reference uses
+ *     linesize[0] for both planes, src/ColorConversion.cu:301; identical when
+ *     the two pitches are equal, which every decoder output satisfies).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_ERR -3
+#define ORC_UNSUPPORTED -2
+#define ORC_MAX_PATTERN 65536
+
+/* enum values: reference include/VideoProcessor.h:20-28, 32-35, 57-62 */
+enum { F_Y800 = 0, F_RGB24 = 1, F_BGR24 = 2, F_NV12 = 3, F_UYVY = 4, F_YUV444 = 5, F_HSV = 6 };
+enum { P_PLANAR = 0, P_MERGED = 1 };
+enum { R_NEAREST = 0, R_BILINEAR = 1, R_BICUBIC = 2, R_AREA = 3 };
+
+typedef struct {
+    const uint8_t *y, *uv;
+    int pitch_y, pitch_uv;
+    int w, h;
+    /* bounds of the underlying allocations, for the defined-as-zero OOB rule */
+    long y_len, uv_len;
+} plane_t;
+
+static inline int rd(const uint8_t *p, long idx, long len) {
+    return (idx >= 0 && idx < len) ? p[idx] : 0;
+}
+
+/* ------------------------------------------------------------------ crop */
+/* reference src/Crop.cu:4-21: tight copy; chroma pair index is (j & ~1) + left,
+ * so an odd `left` shifts which byte lands in the U slot. */
+static void crop_stage(const plane_t *s, int l, int t, int r, int b, uint8_t *oy, uint8_t *ouv, long ouv_len, int nthreads) {
+    int cw = r - l, ch = b - t;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int i = 0; i < ch; i++) {
+        for (int j = 0; j < cw; j++) {
+            int row = i / 2;
+            int col = (j % 2 == 0) ? j : j - 1;
+            long su = (long)(t / 2 + row) * s->pitch_uv + (col + l);
+            long du = (long)row * cw + col;
+            oy[(long)j + (long)i * cw] = (uint8_t)rd(s->y, (long)(l + j) + (long)(t + i) * s->pitch_y, s->y_len);
+            if (du < ouv_len) ouv[du] = (uint8_t)rd(s->uv, su, s->uv_len);
+            if (du + 1 < ouv_len) ouv[du + 1] = (uint8_t)rd(s->uv, su + 1, s->uv_len);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- resize */
+/* reference src/Resize.cu:5-25 (note the float start index and float compares) */
+static int bilinear_tap(const uint8_t *d, long len, float x, float y, int xd, int yd, int ls, int w, int h, float wx, float wy) {
+    float fidx = y * (float)ls;
+    fidx = x + fidx;
+    int start = (int)fidx;
+    if (x + (float)xd >= (float)w) xd = 0;
+    if (y + (float)yd >= (float)h) ls = 0;
+    int A = rd(d, start, len);
+    int B = rd(d, (long)start + xd, len);
+    int C = rd(d, (long)start + (long)ls * yd, len);
+    int D = rd(d, (long)start + (long)ls * yd + xd, len);
+    float omx = 1.0f - wx, omy = 1.0f - wy;
+    float t1 = (float)A * omx;
+    t1 = t1 * omy;
+    float t2 = (float)B * wx;
+    t2 = t2 * omy;
+    float t3 = (float)C * wy;
+    t3 = t3 * omx;
+    float t4 = wx * wy;
+    t4 = (float)D * t4;
+    float sum = t1 + t2;
+    sum = sum + t3;
+    sum = sum + t4;
+    return (int)sum;
+}
+
+/* reference src/Resize.cu:27-91.  Keys cubic a = -0.75 in double.
+ * pow(w,2) / pow(w,3): w is a float fraction widened to double (<=24 significant bits), so
+ * w*w is EXACT and (w*w)*w is the correctly rounded cube.  The normative oracle uses those
+ * (platform independent).  oracle/pow_pin.c shows glibc's pow(w,3) differs from the correctly
+ * rounded cube by 1 ulp on 0.24 % of all floats in [0,1) -- and CUDA's pow (<=2 ulp, per its
+ * documentation) is a third function -- so the reference's bicubic is only defined up to that;
+ * vpp_oracle_set_libm_pow(1) switches to libm pow() so tests can show the uint8 results agree. */
+static int g_libm_pow = 0;
+void vpp_oracle_set_libm_pow(int on) { g_libm_pow = on; }
+static void cubic_coeffs(double w, double c[4]) {
+    const double a = -0.75;
+    double w2, w3;
+    if (g_libm_pow) { volatile double two = 2, three = 3; w2 = pow(w, two); w3 = pow(w, three); }
+    else { w2 = w * w; w3 = w2 * w; }
+    c[0] = (a * w - (2 * a) * w2) + a * w3;
+    c[1] = (1 - (a + 3) * w2) + (a + 2) * w3;
+    c[2] = ((-a) * w + (2 * a + 3) * w2) - (a + 2) * w3;
+    c[3] = a * w2 - a * w3;
+}
+
+static int clamp255(int v) {
+    if (v > 255) v = 255;
+    if (v < 0) v = 0;
+    return v;
+}
+
+static int bicubic_tap(const uint8_t *d, long len, int x, int y, int xd, int yd, int ls, int w, int h, double wx, double wy) {
+    long start = (long)x + (long)y * ls;
+    int xdt = xd, ydt = yd;
+    if (x + xd >= w) xd = 0;
+    if (x + xd * 2 >= w) xd = 0;
+    if (x - xdt < 0) xdt = 0;
+    if (y + yd >= h) yd = 0;
+    if (y + yd * 2 >= h) yd = 0;
+    if (y - ydt < 0) ydt = 0;
+    double cx[4], cy[4];
+    cubic_coeffs(wx, cx);
+    cubic_coeffs(wy, cy);
+    long rowoff[4] = { -(long)ls * ydt, 0, (long)ls * yd, 2 * (long)ls * yd };
+    int bv[4];
+    for (int r = 0; r < 4; r++) {
+        long base = start + rowoff[r];
+        double a0 = cx[0] * (double)rd(d, base - xdt, len);
+        double a1 = cx[1] * (double)rd(d, base, len);
+        double a2 = cx[2] * (double)rd(d, base + xd, len);
+        double a3 = cx[3] * (double)rd(d, base + 2 * xd, len);
+        double s = a0 + a1;
+        s = s + a2;
+        s = s + a3;
+        bv[r] = clamp255((int)round(s));
+    }
+    double a0 = cy[0] * (double)bv[0];
+    double a1 = cy[1] * (double)bv[1];
+    double a2 = cy[2] * (double)bv[2];
+    double a3 = cy[3] * (double)bv[3];
+    double s = a0 + a1;
+    s = s + a2;
+    s = s + a3;
+    return clamp255((int)round(s));
+}
+
+/* reference src/Resize.cu:359-386 (host).  Returns number of rows, each row
+ * has `stride` floats of which the kernel consumes the first ceil(scale). */
+static int make_pattern(float scale, float **out, int *stride_out) {
+    int cap = 16, n = 0;
+    int need = (int)ceil((double)scale);
+    int stride = need + 2;
+    float *tab = (float *)calloc((size_t)cap * stride, sizeof(float));
+    float rest = 0;
+    int id = 0;
+    for (;;) {
+        float prod = (float)id * scale;
+        int cont = (prod == 0) || ((prod - (float)(int)prod) > FLT_EPSILON);
+        if (!cont) break;
+        if (n >= ORC_MAX_PATTERN) { free(tab); return -1; }
+        if (n == cap) {
+            cap *= 2;
+            tab = (float *)realloc(tab, (size_t)cap * stride * sizeof(float));
+            memset(tab + (size_t)n * stride, 0, (size_t)(cap - n) * stride * sizeof(float));
+        }
+        float *row = tab + (size_t)n * stride;
+        int k = 0;
+        float dyn = scale;
+        if (rest != 0) {
+            row[k++] = rest;
+            dyn = dyn - rest;
+        }
+        while (dyn - 1 > 0) {
+            if (k < stride) row[k] = 1;
+            k++;
+            dyn = dyn - 1;
+        }
+        if (dyn > FLT_EPSILON) {
+            if (k < stride) row[k] = dyn;
+            k++;
+            rest = 1 - dyn;
+        }
+        /* zero padding up to ceil(scale) is implicit (calloc) */
+        n++;
+        id++;
+    }
+    *out = tab;
+    *stride_out = stride;
+    return n;
+}
+
+/* reference src/Resize.cu:160-178 */
+static int area_tap(const uint8_t *d, long len, long start, float sx, float sy, int ls, int stride, const float *px, const float *py) {
+    float sum = 0, div = 0;
+    int rx = (int)ceilf(sx), ry = (int)ceilf(sy);
+    for (int i = 0; i < ry; i++) {
+        for (int j = 0; j < rx; j++) {
+            long idx = start + (long)j * stride + (long)i * ls;
+            float wgt = px[j] * py[i];
+            div = div + wgt;
+            float v = (float)rd(d, idx, len) * wgt;
+            sum = sum + v;
+        }
+    }
+    sum = sum / div;
+    return (int)sum;
+}
+
+static int resize_stage(const plane_t *s, int dw, int dh, int type, uint8_t *oy, uint8_t *ouv, long ouv_len, int nthreads) {
+    /* reference src/Resize.cu:418-421 */
+    float xr = (float)s->w / (float)dw;
+    float yr = (float)s->h / (float)dh;
+    int sw = s->w, sh = s->h, py = s->pitch_y, puv = s->pitch_uv;
+    const uint8_t *Y = s->y, *UV = s->uv;
+    long yl = s->y_len, uvl = s->uv_len;
+    int ch = dh / 2, cw = dw / 2;
+#define PUT_UV(i, j, u, v)                                                      \
+    do {                                                                        \
+        long o_ = (long)(i)*dw + 2L * (j);                                      \
+        if (o_ < ouv_len) ouv[o_] = (uint8_t)(u);                               \
+        if (o_ + 1 < ouv_len) ouv[o_ + 1] = (uint8_t)(v);                       \
+    } while (0)
+
+    if (type == R_NEAREST) { /* src/Resize.cu:242-267 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (int i = 0; i < dh; i++)
+            for (int j = 0; j < dw; j++) {
+                int y = (int)(yr * (float)(unsigned)i);
+                int x = (int)(xr * (float)(unsigned)j);
+                oy[(long)i * dw + j] = (uint8_t)rd(Y, (long)y * py + x, yl);
+                if (i < ch && j < cw)
+                    PUT_UV(i, j, rd(UV, (long)y * puv + 2 * x, uvl), rd(UV, (long)y * puv + 2 * x + 1, uvl));
+            }
+    } else if (type == R_BILINEAR) { /* src/Resize.cu:269-312 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (int i = 0; i < dh; i++)
+            for (int j = 0; j < dw; j++) {
+                float yf = ((float)(unsigned)i + 0.5f) * yr;
+                yf = yf - 0.5f;
+                float xf = ((float)(unsigned)j + 0.5f) * xr;
+                xf = xf - 0.5f;
+                int x = (int)floorf(xf), y = (int)floorf(yf);
+                float wx = xf - (float)x, wy = yf - (float)y;
+                if (x < 0) { x = 0; wx = 0; }
+                if (y < 0) { y = 0; wy = 0; }
+                if (x > sw - 1) { x = sw - 1; wx = 0; }
+                if (y > sh - 1) { y = sh - 1; wy = 0; }
+                oy[(long)i * dw + j] = (uint8_t)bilinear_tap(Y, yl, (float)x, (float)y, 1, 1, py, sw, sh, wx, wy);
+                if (i < ch && j < cw) {
+                    int u = bilinear_tap(UV, uvl, (float)(2 * x), (float)y, 2, 1, puv, sw, sh / 2, wx, wy);
+                    int v = bilinear_tap(UV, uvl, (float)(2 * x + 1), (float)y, 2, 1, puv, sw, sh / 2, wx, wy);
+                    PUT_UV(i, j, u, v);
+                }
+            }
+    } else if (type == R_BICUBIC) { /* src/Resize.cu:314-357 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (int i = 0; i < dh; i++)
+            for (int j = 0; j < dw; j++) {
+                float yff = ((float)(unsigned)i + 0.5f) * yr;
+                yff = yff - 0.5f;
+                float xff = ((float)(unsigned)j + 0.5f) * xr;
+                xff = xff - 0.5f;
+                double yf = (double)yff, xf = (double)xff;
+                int x = (int)floor(xf), y = (int)floor(yf);
+                double wx = xf - x, wy = yf - y;
+                if (x < 0) { x = 0; wx = 0; }
+                if (y < 0) { y = 0; wy = 0; }
+                if (x > sw - 1) { x = sw - 1; wx = 0; }
+                if (y > sh - 1) { y = sh - 1; wy = 0; }
+                oy[(long)i * dw + j] = (uint8_t)bicubic_tap(Y, yl, x, y, 1, 1, py, sw, sh, wx, wy);
+                if (i < ch && j < cw) {
+                    int u = bicubic_tap(UV, uvl, 2 * x, y, 2, 1, puv, sw, sh / 2, wx, wy);
+                    int v = bicubic_tap(UV, uvl, 2 * x + 1, y, 2, 1, puv, sw, sh / 2, wx, wy);
+                    PUT_UV(i, j, u, v);
+                }
+            }
+    } else if (type == R_AREA) {
+        if (xr > 1 && yr > 1) { /* src/Resize.cu:435-452, 180-212 */
+            float *patx = NULL, *paty = NULL;
+            int stx = 0, sty = 0;
+            int nx = make_pattern(xr, &patx, &stx);
+            int ny = make_pattern(yr, &paty, &sty);
+            if (nx <= 0 || ny <= 0) { free(patx); free(paty); return ORC_UNSUPPORTED; }
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+            for (int i = 0; i < dh; i++)
+                for (int j = 0; j < dw; j++) {
+                    float yf = (float)(int)(yr * (float)(unsigned)i);
+                    float xf = (float)(int)(xr * (float)(unsigned)j);
+                    int x = (int)floorf(xf), y = (int)floorf(yf);
+                    const float *rx = patx + (size_t)(j % nx) * stx;
+                    const float *ry = paty + (size_t)(i % ny) * sty;
+                    oy[(long)i * dw + j] = (uint8_t)area_tap(Y, yl, (long)y * py + x, xr, yr, py, 1, rx, ry);
+                    if (i < ch && j < cw) {
+                        long idx = (long)y * puv + 2L * x;
+                        int u = area_tap(UV, uvl, idx, xr, yr, puv, 2, rx, ry);
+                        int v = area_tap(UV, uvl, idx + 1, xr, yr, puv, 2, rx, ry);
+                        PUT_UV(i, j, u, v);
+                    }
+                }
+            free(patx);
+            free(paty);
+        } else { /* src/Resize.cu:214-240 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+            for (int i = 0; i < dh; i++)
+                for (int j = 0; j < dw; j++) {
+                    int x = (int)floorf(xr * (float)(unsigned)j);
+                    float q = (float)(x + 1) / xr;
+                    float fx = (float)((unsigned)j + 1u) - q;
+                    if (fx <= 0) fx = 0; else fx = fx - floorf(fx);
+                    int y = (int)floorf(yr * (float)(unsigned)i);
+                    q = (float)(y + 1) / yr;
+                    float fy = (float)((unsigned)i + 1u) - q;
+                    if (fy <= 0) fy = 0; else fy = fy - floorf(fy);
+                    oy[(long)i * dw + j] = (uint8_t)bilinear_tap(Y, yl, (float)x, (float)y, 1, 1, py, sw, sh, fx, fy);
+                    if (i < ch && j < cw) {
+                        int u = bilinear_tap(UV, uvl, (float)(2 * x), (float)y, 2, 1, puv, sw, sh / 2, fx, fy);
+                        int v = bilinear_tap(UV, uvl, (float)(2 * x + 1), (float)y, 2, 1, puv, sw, sh / 2, fx, fy);
+                        PUT_UV(i, j, u, v);
+                    }
+                }
+        }
+    } else {
+        return ORC_UNSUPPORTED; /* reference launches nothing: output undefined */
+    }
+#undef PUT_UV
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- colour */
+/* reference src/ColorConversion.cu:6-39.  BT.601 limited range, fp32, trunc. */
+static void yuv2rgb(int Yv, int U, int V, int *R, int *G, int *B) {
+    float yl = (float)Yv - 16.f;
+    if (!(yl > 0.f)) yl = 0.f;
+    float yv = yl * 1.163999557f;
+    float rv = 1.5959997177f * (float)(V - 128);
+    rv = rv + 0.5f;
+    *R = clamp255((int)(yv + rv));
+    float bv = 2.017999649f * (float)(U - 128);
+    bv = bv + 0.5f;
+    *B = clamp255((int)(yv + bv));
+    float g1 = -0.812999725f * (float)(V - 128);
+    float g2 = 0.390999794f * (float)(U - 128);
+    float gv = g1 - g2;
+    gv = gv + 0.5f;
+    *G = clamp255((int)(yv + gv));
+}
+
+#define STORE(T, buf, idx, val, norm)                 \
+    do {                                              \
+        T v_ = (T)(val);                              \
+        if (norm) v_ = (T)(v_ / 255);                 \
+        ((T *)(buf))[idx] = v_;                       \
+    } while (0)
+
+/* uchar "/= 255" is integer division (reference templates instantiate it). */
+#define RGB_BODY(T)                                                                               \
+    for (int i = 0; i < h; i++)                                                                   \
+        for (int j = 0; j < w; j++) {                                                             \
+            long urow = (long)(i / 2) * s->pitch_uv;                                              \
+            int ucol = (j % 2 == 0) ? j : j - 1;                                                  \
+            int U = rd(s->uv, urow + ucol, s->uv_len), V = rd(s->uv, urow + ucol + 1, s->uv_len); \
+            int R, G, B;                                                                          \
+            yuv2rgb(rd(s->y, (long)j + (long)i * s->pitch_y, s->y_len), U, V, &R, &G, &B);        \
+            int c0 = swap ? B : R, c2 = swap ? R : B;                                             \
+            if (planes == P_PLANAR) {                                                             \
+                long p = (long)j + (long)i * w, pl = (long)w * h;                                 \
+                STORE(T, out, p, c0, norm);                                                       \
+                STORE(T, out, p + pl, G, norm);                                                   \
+                STORE(T, out, p + 2 * pl, c2, norm);                                              \
+            } else {                                                                              \
+                long p = 3L * j + (long)i * 3 * w;                                                \
+                STORE(T, out, p, c0, norm);                                                       \
+                STORE(T, out, p + 1, G, norm);                                                    \
+                STORE(T, out, p + 2, c2, norm);                                                   \
+            }                                                                                     \
+        }
+
+/* reference src/ColorConversion.cu:41-93 (planar / merged), 300-330 (host) */
+static void rgb_stage(const plane_t *s, int swap, int planes, int norm, int is_float, void *out, int nthreads) {
+    int w = s->w, h = s->h;
+    if (is_float) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        RGB_BODY(float)
+    } else {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        RGB_BODY(uint8_t)
+    }
+}
+
+/* reference src/ColorConversion.cu:107-127 */
+static int uyvy_chroma(const plane_t *s, int i, int j, int height) {
+    int pitch = s->pitch_uv;
+    int row = i / 2;
+    int v = rd(s->uv, (long)j + (long)row * pitch, s->uv_len);
+    if (row % 2 != 0) {
+        int p2 = row + 1 < height / 2 - 1 ? row + 1 : height / 2 - 1;
+        int p3 = row - 1 > 0 ? row - 1 : 0;
+        int p4 = row + 2 < height / 2 - 1 ? row + 2 : height / 2 - 1;
+        int a = rd(s->uv, (long)row * pitch + j, s->uv_len) + rd(s->uv, (long)p2 * pitch + j, s->uv_len);
+        int b = rd(s->uv, (long)p3 * pitch + j, s->uv_len) + rd(s->uv, (long)p4 * pitch + j, s->uv_len);
+        v = clamp255((9 * a - b + 8) >> 4);
+    }
+    return v & 0xff;
+}
+
+/* reference src/ColorConversion.cu:177-209 */
+#define UYVY_BODY(T)                                                              \
+    for (int i = 0; i < h; i++)                                                   \
+        for (int j = 0; j < w; j++) {                                             \
+            long idx = (long)j + (long)i * w;                                     \
+            int yv = rd(s->y, (long)j + (long)i * s->pitch_y, s->y_len);          \
+            if (idx % 2 == 0) {                                                   \
+                STORE(T, out, idx * 2, uyvy_chroma(s, i, j, h), norm);     \
+                STORE(T, out, idx * 2 + 1, yv, norm);                             \
+                STORE(T, out, idx * 2 + 2, uyvy_chroma(s, i, j + 1, h), norm); \
+            } else {                                                              \
+                STORE(T, out, idx * 2 + 1, yv, norm);                             \
+            }                                                                     \
+        }
+
+static void uyvy_stage(const plane_t *s, int norm, int is_float, void *out) {
+    int w = s->w, h = s->h;
+    if (is_float) { UYVY_BODY(float) } else { UYVY_BODY(uint8_t) }
+}
+
+/* reference src/ColorConversion.cu:129-173.  uchar: integer /16 then wrap to
+ * uchar; float: true division, no flooring. */
+static float h444_f(const float *src, long n, long index, int shift, int w, int h) {
+    long p1 = index - 3 + shift, p2 = index + 1 + shift, p3 = index - 7 + shift, p4 = index + 5 + shift;
+    if (p3 < 0) p3 = p1;
+    if (p4 > (long)w * h * 2 - 1) p4 = p2;
+#define G_(p) (((p) >= 0 && (p) < n) ? src[p] : 0.0f)
+    float a = G_(p1) + G_(p2);
+    a = 9 * a;
+    float b = G_(p3) + G_(p4);
+    float v = a - b;
+    v = v + 8;
+    v = v / 16;
+#undef G_
+    if (v > 255.0f) v = 255.0f;
+    if (v < 0.0f) v = 0.0f;
+    return v;
+}
+static uint8_t h444_u(const uint8_t *src, long n, long index, int shift, int w, int h) {
+    long p1 = index - 3 + shift, p2 = index + 1 + shift, p3 = index - 7 + shift, p4 = index + 5 + shift;
+    if (p3 < 0) p3 = p1;
+    if (p4 > (long)w * h * 2 - 1) p4 = p2;
+    int v = (9 * (rd(src, p1, n) + rd(src, p2, n)) - (rd(src, p3, n) + rd(src, p4, n)) + 8) / 16;
+    return (uint8_t)v; /* min/max on uchar are no-ops */
+}
+
+static void yuv444_stage(const plane_t *s, int norm, int is_float, void *out) {
+    int w = s->w, h = s->h;
+    long n = (long)w * h * 2, wh = (long)w * h;
+    if (is_float) {
+        float *tmp = (float *)calloc((size_t)n + 4, sizeof(float));
+        uyvy_stage(s, 0, 1, tmp);
+        float *o = (float *)out;
+        for (long idx = 0; idx < wh; idx++) {
+            long si = idx * 2 + 1;
+            float yv = tmp[si], u, v;
+            if (idx % 2 == 0) { u = tmp[si - 1]; v = (si + 1 < n) ? tmp[si + 1] : 0.0f; }
+            else { u = h444_f(tmp, n, si, 0, w, h); v = h444_f(tmp, n, si, 2, w, h); }
+            if (norm) { yv = yv / 255; u = u / 255; v = v / 255; }
+            o[idx] = yv; o[wh + idx] = u; o[2 * wh + idx] = v;
+        }
+        free(tmp);
+    } else {
+        uint8_t *tmp = (uint8_t *)calloc((size_t)n + 4, 1);
+        uyvy_stage(s, 0, 0, tmp);
+        uint8_t *o = (uint8_t *)out;
+        for (long idx = 0; idx < wh; idx++) {
+            long si = idx * 2 + 1;
+            uint8_t yv = tmp[si], u, v;
+            if (idx % 2 == 0) { u = tmp[si - 1]; v = (si + 1 < n) ? tmp[si + 1] : 0; }
+            else { u = h444_u(tmp, n, si, 0, w, h); v = h444_u(tmp, n, si, 2, w, h); }
+            if (norm) { yv = yv / 255; u = u / 255; v = v / 255; }
+            o[idx] = yv; o[wh + idx] = u; o[2 * wh + idx] = v;
+        }
+        free(tmp);
+    }
+}
+
+/* reference src/ColorConversion.cu:235-278 on the output of the normalised
+ * merged RGB kernel (host code :357-370). */
+static void hsv_stage(const plane_t *s, float *out, int nthreads) {
+    int w = s->w, h = s->h;
+    float *rgb = (float *)malloc((size_t)w * h * 3 * sizeof(float));
+    rgb_stage(s, 0, P_MERGED, 1, 1, rgb, nthreads);
+    for (long p = 0; p < (long)w * h; p++) {
+        float R = rgb[3 * p], G = rgb[3 * p + 1], B = rgb[3 * p + 2];
+        float mn = R < G ? R : G; mn = mn < B ? mn : B;
+        float mx = R > G ? R : G; mx = mx > B ? mx : B;
+        float delta = mx - mn;
+        float *H = &out[3 * p], *S = &out[3 * p + 1], *V = &out[3 * p + 2];
+        *V = mx;
+        *S = 0;
+        if (mx != 0) { float q = mn / mx; *S = 1 - q; }
+        if (mx == mn) { *H = 0; continue; }
+        float hv = 0;
+        if (R == mx && G >= B) { hv = 60 * (G - B); hv = hv / delta; }
+        else if (R == mx && G < B) { hv = 60 * (G - B); hv = hv / delta; hv = hv + 360; }
+        else if (G == mx) { hv = 60 * (B - R); hv = hv / delta; hv = hv + 120; }
+        else if (B == mx) { hv = 60 * (R - G); hv = hv / delta; hv = hv + 240; }
+        if (hv < 0) hv = hv + 360;
+        hv = hv / 360;
+        *H = hv;
+    }
+    free(rgb);
+}
+
+static int color_stage(const plane_t *s, int fourcc, int planes, int norm, void *out, int nthreads) {
+    int w = s->w, h = s->h;
+    int is_float = norm ? 1 : 0;
+    switch (fourcc) {
+    case F_RGB24: rgb_stage(s, 0, planes, norm, is_float, out, nthreads); return ORC_OK;
+    case F_BGR24: rgb_stage(s, 1, planes, norm, is_float, out, nthreads); return ORC_OK;
+    case F_Y800: /* src/ColorConversion.cu:95-105 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int v = rd(s->y, (long)j + (long)i * s->pitch_y, s->y_len);
+                if (is_float) STORE(float, out, (long)j + (long)i * w, v, norm);
+                else STORE(uint8_t, out, (long)j + (long)i * w, v, norm);
+            }
+        return ORC_OK;
+    case F_UYVY: uyvy_stage(s, norm, is_float, out); return ORC_OK;
+    case F_YUV444: yuv444_stage(s, norm, is_float, out); return ORC_OK;
+    case F_NV12: /* src/ColorConversion.cu:211-233 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                long idx = (long)j + (long)i * w;
+                int v = rd(s->y, (long)j + (long)i * s->pitch_y, s->y_len);
+                if (is_float) STORE(float, out, idx, v, norm); else STORE(uint8_t, out, idx, v, norm);
+                if (i % 2 == 0 && j % 2 == 0) {
+                    long iu = (long)(i / 2) * w + j, su = (long)(i / 2) * s->pitch_uv + j;
+                    int u = rd(s->uv, su, s->uv_len), vv = rd(s->uv, su + 1, s->uv_len);
+                    if (is_float) { STORE(float, out, (long)w * h + iu, u, norm); STORE(float, out, (long)w * h + iu + 1, vv, norm); }
+                    else { STORE(uint8_t, out, (long)w * h + iu, u, norm); STORE(uint8_t, out, (long)w * h + iu + 1, vv, norm); }
+                }
+            }
+        return ORC_OK;
+    case F_HSV: hsv_stage(s, (float *)out, nthreads); return ORC_OK;
+    default: return ORC_ERR;
+    }
+}
+
+/* ---------------------------------------------------------- public entry */
+/* channel count, reference src/VideoProcessor.cpp:4-14 */
+float vpp_oracle_channels(int fourcc) {
+    if (fourcc == F_Y800) return 1.f;
+    if (fourcc == F_UYVY) return 2.f;
+    if (fourcc == F_NV12) return 1.5f;
+    return 3.f;
+}
+
+/* Stage-level entries (tight outputs, like the reference's intermediates). */
+int vpp_oracle_crop(const uint8_t *y, const uint8_t *uv, int pitch_y, int pitch_uv, int w, int h,
+                    int l, int t, int r, int b, uint8_t *oy, uint8_t *ouv) {
+    plane_t s = { y, uv, pitch_y ? pitch_y : w, pitch_uv ? pitch_uv : w, w, h, 0, 0 };
+    s.y_len = (long)s.pitch_y * h;
+    s.uv_len = (long)s.pitch_uv * (h / 2);
+    crop_stage(&s, l, t, r, b, oy, ouv, (long)(r - l) * ((b - t) / 2), 1);
+    return ORC_OK;
+}
+
+int vpp_oracle_resize(const uint8_t *y, const uint8_t *uv, int pitch_y, int pitch_uv, int w, int h,
+                      int dw, int dh, int type, uint8_t *oy, uint8_t *ouv, int nthreads) {
+    plane_t s = { y, uv, pitch_y ? pitch_y : w, pitch_uv ? pitch_uv : w, w, h, 0, 0 };
+    s.y_len = (long)s.pitch_y * h;
+    s.uv_len = (long)s.pitch_uv * (h / 2);
+    return resize_stage(&s, dw, dh, type, oy, ouv, (long)dw * (dh / 2), nthreads < 1 ? 1 : nthreads);
+}
+
+/* AREA weight table, exported so tests can pin the product's host-side table
+ * against this restatement.  Returns rows (or -1); table is rows x stride. */
+int vpp_oracle_area_pattern(float scale, float *out, int max_floats, int *stride) {
+    float *tab = NULL;
+    int st = 0;
+    int n = make_pattern(scale, &tab, &st);
+    if (n > 0 && (long)n * st <= max_floats) memcpy(out, tab, (size_t)n * st * sizeof(float));
+    free(tab);
+    *stride = st;
+    return n;
+}
+
+/* Whole Convert(): reference src/VideoProcessor.cpp:94-151.
+ * `out` is tight, channels*W*H elements of uint8 (normalization==0) or float. */
+int vpp_oracle_convert(const uint8_t *y, const uint8_t *uv, int pitch_y, int pitch_uv, int w, int h,
+                       int crop_l, int crop_t, int crop_r, int crop_b,
+                       int dst_w, int dst_h, int resize_type,
+                       int fourcc, int planes, int normalization,
+                       void *out, int *out_w, int *out_h, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    plane_t cur = { y, uv, pitch_y ? pitch_y : w, pitch_uv ? pitch_uv : w, w, h, 0, 0 };
+    cur.y_len = (long)cur.pitch_y * h;
+    cur.uv_len = (long)cur.pitch_uv * (h / 2);
+    uint8_t *cy = NULL, *cuv = NULL, *ry = NULL, *ruv = NULL;
+    int sts = ORC_OK;
+
+    int cw = crop_r - crop_l, chh = crop_b - crop_t;
+    int crop = (cw > 0 && chh > 0 && cw < w && chh < h);
+    if (crop) {
+        cy = (uint8_t *)calloc((size_t)cw * chh + 16, 1);
+        cuv = (uint8_t *)calloc((size_t)cw * (chh / 2) + 16, 1);
+        crop_stage(&cur, crop_l, crop_t, crop_r, crop_b, cy, cuv, (long)cw * (chh / 2), nthreads);
+        plane_t n = { cy, cuv, cw, cw, cw, chh, (long)cw * chh, (long)cw * (chh / 2) };
+        cur = n;
+    }
+    int resize = 0;
+    if (dst_w && dst_h && (dst_w != cur.w || dst_h != cur.h)) resize = 1;
+    if (resize) {
+        ry = (uint8_t *)calloc((size_t)dst_w * dst_h + 16, 1);
+        ruv = (uint8_t *)calloc((size_t)dst_w * (dst_h / 2) + 16, 1);
+        sts = resize_stage(&cur, dst_w, dst_h, resize_type, ry, ruv, (long)dst_w * (dst_h / 2), nthreads);
+        plane_t n = { ry, ruv, dst_w, dst_w, dst_w, dst_h, (long)dst_w * dst_h, (long)dst_w * (dst_h / 2) };
+        cur = n;
+    }
+    if (sts == ORC_OK) {
+        /* HSV always runs the <float> kernels (src/ColorConversion.cu:357-370) */
+        sts = color_stage(&cur, fourcc, planes, normalization || fourcc == F_HSV, out, nthreads);
+    }
+    if (out_w) *out_w = cur.w;
+    if (out_h) *out_h = cur.h;
+    free(cy); free(cuv); free(ry); free(ruv);
+    return sts;
+}
+
+/* av_crc(AV_CRC_32_IEEE, -1, buf, n) as used by the reference tests
+ * (tests/src/VPPTests.cpp:92).  [ext] libavutil's AV_CRC_32_IEEE table is the
+ * MSB-first polynomial 0x04C11DB7 run on a byte-swapped (little-endian) state,
+ * no final xor.  UNVERIFIED here (no libavutil in the image). */
+uint32_t vpp_oracle_av_crc32_ieee(uint32_t crc, const uint8_t *buf, long n) {
+    /* state kept byte-swapped: operate MSB-first on bswap(crc), return bswap */
+    uint32_t c = __builtin_bswap32(crc);
+    for (long i = 0; i < n; i++) {
+        c ^= (uint32_t)buf[i] << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+    }
+    return __builtin_bswap32(c);
+}
