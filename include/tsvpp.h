@@ -1,0 +1,141 @@
+/*
+ * tsvpp.h -- C ABI of the MI355X-native Video Post Processing (VPP) path.
+ *
+ * Drop-in boundary for the hot path of osai-ai/tensor-stream:
+ *     NV12 crop -> nearest/bilinear/bicubic/area resize -> YUV->RGB24/BGR24
+ *     (+ fp32 normalise, planar/merged)
+ * i.e. everything that sits behind `VideoProcessor::Convert()`
+ * (reference src/VideoProcessor.cpp:94-166) and its three CUDA launchers
+ * `cropHost` (src/Crop.cu:23-48), `resizeKernel` (src/Resize.cu:408-473) and
+ * `colorConversionKernel<T>` (src/ColorConversion.cu:280-382).
+ *
+ * The reference has no C ABI (its boundary is the C++ class); these entry points
+ * are what a `VideoProcessor` built for ROCm binds instead of the CUDA launchers.
+ * INTEGRATION.md shows the adapter; tensor-stream_amd/cpp/VideoProcessor.{h,cpp}
+ * is that adapter, written out.
+ *
+ * Conventions
+ *   - plain C types only: device pointers are `void*` / `const uint8_t*`, the HIP
+ *     stream is passed as `void*` (a `hipStream_t`; NULL = the null stream);
+ *   - every function returning `int` uses the reference's status convention
+ *     (include/Common.h:19-24): 0 = OK, negative = VREADER_* code, positive = a
+ *     `hipError_t` value (the reference returns `cudaError_t` the same way);
+ *   - all work is enqueued on the given stream and is asynchronous; nothing in the
+ *     per-frame path allocates, frees or synchronises (the reference does 1-5
+ *     cudaMalloc + 0-4 cudaFree per frame, src/VideoProcessor.cpp:94-166);
+ *   - output memory is CALLER-allocated and tight: channels*W*H elements of
+ *     uint8 (normalization == 0) or float (normalization != 0), layout as the
+ *     reference's kernels write it (src/ColorConversion.cu:41-93).
+ */
+#ifndef TSVPP_H
+#define TSVPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: reference include/Common.h:19-24 (enum Internal) ---- */
+#define TSVPP_OK 0
+#define TSVPP_REPEAT (-1)
+#define TSVPP_UNSUPPORTED (-2)
+#define TSVPP_ERROR (-3)
+
+/* ---- enums: byte-compatible with reference include/VideoProcessor.h:20-28,32-35,57-62 ---- */
+enum tsvpp_fourcc { TSVPP_Y800 = 0, TSVPP_RGB24 = 1, TSVPP_BGR24 = 2, TSVPP_NV12 = 3, TSVPP_UYVY = 4, TSVPP_YUV444 = 5, TSVPP_HSV = 6 };
+enum tsvpp_planes { TSVPP_PLANAR = 0, TSVPP_MERGED = 1 };
+enum tsvpp_resize { TSVPP_NEAREST = 0, TSVPP_BILINEAR = 1, TSVPP_BICUBIC = 2, TSVPP_AREA = 3 };
+
+#define TSVPP_MAX_BATCH 64 /* frames per launch; larger batches are split */
+
+/* One NV12 frame in device memory.  Mirrors the AVFrame fields Convert() reads
+ * (reference src/Crop.cu:37-38, src/Resize.cu:420-421, src/ColorConversion.cu:301):
+ * data[0], data[1], linesize[0], linesize[1], width, height.
+ * pitch == 0 means "pitch = width", exactly as the reference's fallback. */
+typedef struct tsvpp_nv12 {
+    const uint8_t *y;  /* AVFrame::data[0] */
+    const uint8_t *uv; /* AVFrame::data[1], interleaved U,V */
+    int32_t pitch_y;   /* AVFrame::linesize[0] */
+    int32_t pitch_uv;  /* AVFrame::linesize[1] */
+    int32_t width;
+    int32_t height;
+} tsvpp_nv12;
+
+/* Flat mirror of FrameParameters {ResizeOptions, ColorOptions, CropOptions}
+ * (reference include/VideoProcessor.h:39-105).  Zero-initialised == the
+ * reference defaults except fourcc/planes (reference: RGB24, MERGED). */
+typedef struct tsvpp_params {
+    int32_t crop_left, crop_top;     /* CropOptions::leftTopCorner  (x, y) */
+    int32_t crop_right, crop_bottom; /* CropOptions::rightBottomCorner (x, y) */
+    int32_t dst_width, dst_height;   /* ResizeOptions::width/height, 0 = no resize */
+    int32_t resize_type;             /* enum tsvpp_resize */
+    int32_t fourcc;                  /* enum tsvpp_fourcc */
+    int32_t planes;                  /* enum tsvpp_planes */
+    int32_t normalization;           /* ColorOptions::normalization */
+} tsvpp_params;
+
+/* The eight colour constants of reference src/ColorConversion.cu:23,25,30,35:
+ * {1.163999557, 1.5959997177, 2.017999649, -0.812999725, -0.390999794, 0.5, 16, 128}.
+ * They are literals in the reference; here they live in the context so that a
+ * multi-GPU job can broadcast one block from rank 0 (RCCL) and every rank can
+ * verify it against the compiled-in defaults. */
+typedef struct tsvpp_coeffs {
+    float y_scale, v_to_r, u_to_b, v_to_g, u_to_g, round_bias, y_offset, c_offset;
+} tsvpp_coeffs;
+
+typedef struct tsvpp_ctx tsvpp_ctx;
+
+/* VideoProcessor::Init (reference src/VideoProcessor.cpp:79-92): selects `device`,
+ * creates `max_consumers` streams for the named-consumer pool.  Unlike the
+ * reference it queries the properties of `device`, not of device 0. */
+int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx);
+/* VideoProcessor::Close (src/VideoProcessor.cpp:168-178) + release of cached tables. */
+void tsvpp_destroy(tsvpp_ctx *ctx);
+
+/* findFree<cudaStream_t>(consumerName, streamArr) (reference include/Common.h:225-237,
+ * src/VideoProcessor.cpp:98-104): the stream bound to `name`, claiming a free slot
+ * for a new name; TSVPP_ERROR when all `max_consumers` slots are taken. */
+int tsvpp_consumer_stream(tsvpp_ctx *ctx, const char *name, void **out_stream);
+
+/* Stage selection of Convert() (reference src/VideoProcessor.cpp:106-135) without
+ * running anything: final width/height and the tight output size in bytes. */
+int tsvpp_out_dims(const tsvpp_params *p, int in_width, int in_height, int *out_width, int *out_height);
+size_t tsvpp_out_bytes(const tsvpp_params *p, int in_width, int in_height);
+/* channelsByFourCC (reference src/VideoProcessor.cpp:4-14). */
+float tsvpp_channels(int fourcc);
+
+/* VideoProcessor::Convert for one frame, as ONE fused kernel launch on `stream`.
+ * `out` must hold tsvpp_out_bytes() bytes. */
+int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, void *out, void *stream);
+
+/* The same conversion for `n` independent frames of identical geometry, in
+ * ceil(n / TSVPP_MAX_BATCH) launches.  `in` and `outs` are HOST arrays of n entries.
+ * (Not in the reference: one 1080p frame is ~2.5 us of HBM time, below a launch.) */
+int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream);
+
+/* Pre-build everything a (params, input size) pair needs (AREA weight tables) so that
+ * later tsvpp_convert* calls for it touch no allocator -- e.g. before graph capture. */
+int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height);
+
+/* Colour constants: read the active block, replace it (e.g. with the block received
+ * from rank 0), restore the defaults. */
+int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out);
+int tsvpp_set_coeffs(tsvpp_ctx *ctx, const tsvpp_coeffs *in);
+void tsvpp_default_coeffs(tsvpp_coeffs *out);
+
+/* AREA (down-scale) weight table of generateResizePattern (reference
+ * src/Resize.cu:359-386) as this library builds it: writes rows*taps floats
+ * (taps = ceil(scale)) to `out` if it fits `max_floats`; returns rows or <0. */
+int tsvpp_area_pattern(float scale, float *out, int max_floats, int *taps);
+
+/* Human-readable text for a status returned by this library. */
+const char *tsvpp_strerror(int status);
+/* "tsvpp <version> gfx950" */
+const char *tsvpp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSVPP_H */

@@ -1,0 +1,395 @@
+// tsvpp_api.cpp -- host side of the C ABI declared in include/tsvpp.h.
+//
+// Holds what the reference keeps in `class VideoProcessor` (include/VideoProcessor.h:120-149):
+// the per-consumer stream pool, plus what the reference rebuilds on every frame and this
+// library builds once: the AREA weight tables (reference src/Resize.cu:436-452 mallocs, copies
+// and leaks them per frame).  No per-frame allocation, free or synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tsvpp.h"
+#include "vpp_kernels.h"
+
+using namespace tsvpp;
+
+namespace {
+
+struct AreaTable {
+    float *dev = nullptr;
+    int rows = 0, taps = 0;
+};
+
+constexpr int kMaxPatternRows = 65536; // the reference's generator has no bound (can spin forever)
+
+// Weight rows of the AREA down-scale, semantics of generateResizePattern (reference
+// src/Resize.cu:359-386) in plain float arithmetic.  Each row is emitted with exactly
+// taps = ceil(scale) entries: the device code never reads further (src/Resize.cu:162-169),
+// so a row's optional (taps+1)-th entry is dropped here instead of being uploaded.
+bool build_area_rows(float scale, std::vector<float> &tab, int &rows, int &taps) {
+    taps = (int)std::ceil((double)scale);
+    rows = 0;
+    tab.clear();
+    if (!(scale > 1.0f) || taps < 1) return false;
+    float carry = 0.0f; // part of the next source pixel already consumed by the previous row
+    for (int k = 0;; k++) {
+        const float pos = (float)k * scale;
+        const bool more = (pos == 0.0f) || (pos - (float)(int)pos > FLT_EPSILON);
+        if (!more) break;
+        if (rows >= kMaxPatternRows) return false;
+        std::vector<float> row;
+        float left = scale;
+        if (carry != 0.0f) {
+            row.push_back(carry);
+            left = left - carry;
+        }
+        while (left - 1.0f > 0.0f) {
+            row.push_back(1.0f);
+            left = left - 1.0f;
+        }
+        if (left > FLT_EPSILON) {
+            row.push_back(left);
+            carry = 1.0f - left;
+        }
+        row.resize((size_t)taps, 0.0f); // pads short rows with 0, truncates long ones
+        tab.insert(tab.end(), row.begin(), row.end());
+        rows++;
+    }
+    return rows > 0;
+}
+
+struct Plan {
+    Mode mode = M_NONE;
+    OutKind out = O_U8_MERGED;
+    int off_x = 0, off_y = 0; // crop origin
+    int src_w = 0, src_h = 0; // logical source after crop
+    int dst_w = 0, dst_h = 0;
+    float xr = 1.f, yr = 1.f;
+    int swap_rb = 0;
+    size_t out_bytes = 0;
+};
+
+} // namespace
+
+struct tsvpp_ctx {
+    int device = 0;
+    std::vector<std::pair<std::string, hipStream_t>> streams;
+    std::mutex stream_mu;
+    tsvpp_coeffs coeffs;
+    std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
+    std::mutex area_mu;
+};
+
+namespace {
+
+// Stage selection of VideoProcessor::Convert (reference src/VideoProcessor.cpp:106-142).
+int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
+    if (!p || in_w <= 0 || in_h <= 0) return TSVPP_ERROR;
+    if ((in_w | in_h) & 1) return TSVPP_UNSUPPORTED; // NV12 needs even sizes (reference: undefined)
+    const int cw = p->crop_right - p->crop_left, ch = p->crop_bottom - p->crop_top;
+    // crop only if the box is strictly smaller in BOTH dimensions (src/VideoProcessor.cpp:109)
+    const bool crop = cw > 0 && ch > 0 && cw < in_w && ch < in_h;
+    pl.src_w = in_w;
+    pl.src_h = in_h;
+    pl.off_x = pl.off_y = 0;
+    if (crop) {
+        if (p->crop_left < 0 || p->crop_top < 0 || p->crop_right > in_w || p->crop_bottom > in_h) return TSVPP_ERROR;
+        if ((cw | ch) & 1) return TSVPP_UNSUPPORTED; // reference writes chroma out of bounds here
+        pl.src_w = cw;
+        pl.src_h = ch;
+        pl.off_x = p->crop_left;
+        pl.off_y = p->crop_top;
+    }
+    pl.dst_w = pl.src_w;
+    pl.dst_h = pl.src_h;
+    pl.mode = M_NONE;
+    pl.xr = pl.yr = 1.0f;
+    if (p->dst_width < 0 || p->dst_height < 0) return TSVPP_ERROR;
+    if (p->dst_width && p->dst_height && (p->dst_width != pl.src_w || p->dst_height != pl.src_h)) {
+        if ((p->dst_width | p->dst_height) & 1) return TSVPP_UNSUPPORTED; // reference leaves chroma unwritten
+        pl.dst_w = p->dst_width;
+        pl.dst_h = p->dst_height;
+        pl.xr = (float)pl.src_w / (float)pl.dst_w; // src/Resize.cu:418-419
+        pl.yr = (float)pl.src_h / (float)pl.dst_h;
+        switch (p->resize_type) {
+        case TSVPP_NEAREST: pl.mode = M_NEAREST; break;
+        case TSVPP_BILINEAR: pl.mode = M_BILINEAR; break;
+        case TSVPP_BICUBIC: pl.mode = M_BICUBIC; break;
+        case TSVPP_AREA: pl.mode = (pl.xr > 1.0f && pl.yr > 1.0f) ? M_AREA_DOWN : M_AREA_UP; break; // src/Resize.cu:435
+        default: return TSVPP_UNSUPPORTED; // reference launches nothing and returns garbage
+        }
+    }
+    switch (p->fourcc) {
+    case TSVPP_RGB24: pl.swap_rb = 0; break;
+    case TSVPP_BGR24: pl.swap_rb = 1; break;
+    default: return TSVPP_UNSUPPORTED;
+    }
+    if (p->planes != TSVPP_PLANAR && p->planes != TSVPP_MERGED) return TSVPP_UNSUPPORTED;
+    const bool f32 = p->normalization != 0; // src/VideoProcessor.cpp:139-142
+    pl.out = f32 ? (p->planes == TSVPP_PLANAR ? O_F32_PLANAR : O_F32_MERGED)
+                 : (p->planes == TSVPP_PLANAR ? O_U8_PLANAR : O_U8_MERGED);
+    pl.out_bytes = (size_t)3 * (size_t)pl.dst_w * (size_t)pl.dst_h * (f32 ? sizeof(float) : 1);
+    return TSVPP_OK;
+}
+
+int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
+    uint32_t key;
+    std::memcpy(&key, &scale, 4);
+    std::lock_guard<std::mutex> lk(ctx->area_mu);
+    auto it = ctx->area.find(key);
+    if (it != ctx->area.end()) {
+        out = it->second;
+        return TSVPP_OK;
+    }
+    std::vector<float> tab;
+    AreaTable t;
+    if (!build_area_rows(scale, tab, t.rows, t.taps)) return TSVPP_UNSUPPORTED;
+    hipError_t e = hipMalloc((void **)&t.dev, tab.size() * sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(t.dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t.dev);
+        return (int)e;
+    }
+    ctx->area[key] = t;
+    out = t;
+    return TSVPP_OK;
+}
+
+int ensure_device(const tsvpp_ctx *ctx) {
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return (int)e;
+    if (cur != ctx->device) {
+        e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return (int)e;
+    }
+    return TSVPP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void tsvpp_default_coeffs(tsvpp_coeffs *k) {
+    if (!k) return;
+    k->y_scale = 1.163999557f;
+    k->v_to_r = 1.5959997177f;
+    k->u_to_b = 2.017999649f;
+    k->v_to_g = -0.812999725f;
+    k->u_to_g = -0.390999794f;
+    k->round_bias = 0.5f;
+    k->y_offset = 16.0f;
+    k->c_offset = 128.0f;
+}
+
+int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
+    if (!out_ctx || max_consumers < 0) return TSVPP_ERROR;
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return (int)e;
+    if (device < 0 || device >= count) return (int)hipErrorInvalidDevice;
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    tsvpp_ctx *ctx = new tsvpp_ctx();
+    ctx->device = device;
+    tsvpp_default_coeffs(&ctx->coeffs);
+    for (int i = 0; i < max_consumers; i++) {
+        hipStream_t s = nullptr;
+        e = hipStreamCreate(&s); // blocking stream, as the reference (src/VideoProcessor.cpp:86)
+        if (e != hipSuccess) {
+            tsvpp_destroy(ctx);
+            return (int)e;
+        }
+        ctx->streams.emplace_back(std::string("empty"), s);
+    }
+    *out_ctx = ctx;
+    return TSVPP_OK;
+}
+
+void tsvpp_destroy(tsvpp_ctx *ctx) {
+    if (!ctx) return;
+    (void)ensure_device(ctx);
+    for (auto &s : ctx->streams)
+        if (s.second) (void)hipStreamDestroy(s.second);
+    for (auto &a : ctx->area)
+        if (a.second.dev) (void)hipFree(a.second.dev);
+    delete ctx;
+}
+
+int tsvpp_consumer_stream(tsvpp_ctx *ctx, const char *name, void **out_stream) {
+    if (!ctx || !name || !out_stream) return TSVPP_ERROR;
+    std::lock_guard<std::mutex> lk(ctx->stream_mu);
+    for (auto &s : ctx->streams) {
+        if (s.first == name) {
+            *out_stream = (void *)s.second;
+            return TSVPP_OK;
+        }
+        if (s.first == "empty") {
+            s.first = name;
+            *out_stream = (void *)s.second;
+            return TSVPP_OK;
+        }
+    }
+    *out_stream = nullptr;
+    return TSVPP_ERROR; // pool exhausted (reference src/VideoProcessor.cpp:100-103)
+}
+
+float tsvpp_channels(int fourcc) {
+    if (fourcc == TSVPP_Y800) return 1.0f;
+    if (fourcc == TSVPP_UYVY) return 2.0f;
+    if (fourcc == TSVPP_NV12) return 1.5f;
+    return 3.0f;
+}
+
+int tsvpp_out_dims(const tsvpp_params *p, int in_width, int in_height, int *out_width, int *out_height) {
+    Plan pl;
+    int sts = make_plan(p, in_width, in_height, pl);
+    if (sts != TSVPP_OK) return sts;
+    if (out_width) *out_width = pl.dst_w;
+    if (out_height) *out_height = pl.dst_h;
+    return TSVPP_OK;
+}
+
+size_t tsvpp_out_bytes(const tsvpp_params *p, int in_width, int in_height) {
+    Plan pl;
+    if (make_plan(p, in_width, in_height, pl) != TSVPP_OK) return 0;
+    return pl.out_bytes;
+}
+
+int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height) {
+    if (!ctx) return TSVPP_ERROR;
+    Plan pl;
+    int sts = make_plan(p, in_width, in_height, pl);
+    if (sts != TSVPP_OK) return sts;
+    sts = ensure_device(ctx);
+    if (sts != TSVPP_OK) return sts;
+    if (pl.mode == M_AREA_DOWN) {
+        AreaTable t;
+        sts = get_area_table(ctx, pl.xr, t);
+        if (sts != TSVPP_OK) return sts;
+        sts = get_area_table(ctx, pl.yr, t);
+    }
+    return sts;
+}
+
+int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
+    if (!ctx || !in || !p || !outs || n < 0) return TSVPP_ERROR;
+    if (n == 0) return TSVPP_OK;
+    Plan pl;
+    int sts = make_plan(p, in[0].width, in[0].height, pl);
+    if (sts != TSVPP_OK) return sts;
+    const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
+    const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
+    if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
+    bool vec = (pl.dst_w % 4) == 0;
+    for (int f = 0; f < n; f++) {
+        if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
+        if (in[f].width != in[0].width || in[f].height != in[0].height) return TSVPP_UNSUPPORTED;
+        if ((in[f].pitch_y ? in[f].pitch_y : in[f].width) != pitch_y) return TSVPP_UNSUPPORTED;
+        if ((in[f].pitch_uv ? in[f].pitch_uv : in[f].width) != pitch_uv) return TSVPP_UNSUPPORTED;
+        if (((uintptr_t)outs[f] & 15) != 0) vec = false;
+    }
+    sts = ensure_device(ctx);
+    if (sts != TSVPP_OK) return sts;
+
+    LaunchDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.src_w = pl.src_w;
+    d.src_h = pl.src_h;
+    d.pitch_y = pitch_y;
+    d.pitch_uv = pitch_uv;
+    d.dst_w = pl.dst_w;
+    d.dst_h = pl.dst_h;
+    d.xr = pl.xr;
+    d.yr = pl.yr;
+    d.swap_rb = pl.swap_rb;
+    d.k = ctx->coeffs;
+    if (pl.mode == M_AREA_DOWN) {
+        AreaTable tx, ty;
+        sts = get_area_table(ctx, pl.xr, tx);
+        if (sts != TSVPP_OK) return sts;
+        sts = get_area_table(ctx, pl.yr, ty);
+        if (sts != TSVPP_OK) return sts;
+        d.patx = tx.dev;
+        d.nx = tx.rows;
+        d.rx = tx.taps;
+        d.paty = ty.dev;
+        d.ny = ty.rows;
+        d.ry = ty.taps;
+    }
+    // crop = pointer arithmetic (reference src/Crop.cu:10-18: luma at (left + j, top + i), chroma
+    // row top/2 + i/2, chroma byte (j & ~1) + left -- an odd `left` therefore swaps U and V,
+    // exactly as it does in the reference)
+    const size_t y_off = (size_t)pl.off_y * (size_t)pitch_y + (size_t)pl.off_x;
+    const size_t uv_off = (size_t)(pl.off_y / 2) * (size_t)pitch_uv + (size_t)pl.off_x;
+    for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
+        const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
+        FrameTable t;
+        for (int f = 0; f < cnt; f++) {
+            t.y[f] = in[base + f].y + y_off;
+            t.uv[f] = in[base + f].uv + uv_off;
+            t.out[f] = outs[base + f];
+        }
+        for (int f = cnt; f < TSVPP_MAX_BATCH; f++) {
+            t.y[f] = nullptr;
+            t.uv[f] = nullptr;
+            t.out[f] = nullptr;
+        }
+        d.n_frames = cnt;
+        hipError_t e = launch_fused(pl.mode, pl.out, vec, d, t, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return TSVPP_OK;
+}
+
+int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, void *out, void *stream) {
+    void *outs[1] = { out };
+    return tsvpp_convert_batch(ctx, 1, in, p, outs, stream);
+}
+
+int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out) {
+    if (!ctx || !out) return TSVPP_ERROR;
+    *out = ctx->coeffs;
+    return TSVPP_OK;
+}
+
+int tsvpp_set_coeffs(tsvpp_ctx *ctx, const tsvpp_coeffs *in) {
+    if (!ctx || !in) return TSVPP_ERROR;
+    ctx->coeffs = *in;
+    return TSVPP_OK;
+}
+
+int tsvpp_area_pattern(float scale, float *out, int max_floats, int *taps) {
+    std::vector<float> tab;
+    int rows = 0, t = 0;
+    if (!build_area_rows(scale, tab, rows, t)) return TSVPP_UNSUPPORTED;
+    if (taps) *taps = t;
+    if (out && (long)tab.size() <= (long)max_floats) std::memcpy(out, tab.data(), tab.size() * sizeof(float));
+    return rows;
+}
+
+const char *tsvpp_strerror(int status) {
+    switch (status) {
+    case TSVPP_OK: return "ok";
+    case TSVPP_REPEAT: return "VREADER_REPEAT: repeat the request";
+    case TSVPP_UNSUPPORTED: return "VREADER_UNSUPPORTED: unsupported parameters (odd size, unknown FourCC/resize type, mixed batch geometry)";
+    case TSVPP_ERROR: return "VREADER_ERROR: invalid argument or consumer pool exhausted";
+    default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}
+
+const char *tsvpp_version(void) { return "tsvpp 0.1.0 gfx950"; }
+
+} // extern "C"

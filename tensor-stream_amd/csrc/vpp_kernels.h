@@ -1,0 +1,48 @@
+// Launch descriptors shared by the host API (tsvpp_api.cpp) and the gfx950 kernels
+// (vpp_kernels.hip).  Product code -- never includes anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsvpp.h"
+
+namespace tsvpp {
+
+// Resize mode of the fused kernel.  AREA splits in two exactly as the reference's host
+// dispatch does (src/Resize.cu:435): weighted box if both ratios > 1, else the bilinear variant.
+enum Mode : int { M_NONE = 0, M_NEAREST, M_BILINEAR, M_BICUBIC, M_AREA_DOWN, M_AREA_UP, M_COUNT };
+
+// Per-launch pointer table, passed BY VALUE in the kernarg segment (1.5 KiB): the kernel
+// reads its frame's three pointers with scalar loads, no device-side descriptor buffer and
+// no host->device copy per batch.
+struct FrameTable {
+    const uint8_t *y[TSVPP_MAX_BATCH];
+    const uint8_t *uv[TSVPP_MAX_BATCH];
+    void *out[TSVPP_MAX_BATCH];
+};
+
+struct LaunchDesc {
+    // logical source = the crop box if crop is active, else the whole frame; the frame
+    // pointers in FrameTable are already advanced to its top-left corner
+    int src_w, src_h;
+    int pitch_y, pitch_uv;
+    int dst_w, dst_h;
+    float xr, yr; // (float)src_w / dst_w, (float)src_h / dst_h   (src/Resize.cu:418-419)
+    int swap_rb;  // BGR24
+    tsvpp_coeffs k;
+    // AREA-down weight tables: nx rows of rx floats, ny rows of ry floats (rx = ceil(xr))
+    const float *patx, *paty;
+    int nx, ny, rx, ry;
+    // grid decomposition
+    int tiles_x, tiles_y, n_frames;
+    int blocks_per_xcd; // ceil(total_tiles / 8)
+};
+
+// Output flavour: element type x layout.
+enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_COUNT };
+
+// Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
+// store path (needs dst_w % 4 == 0 and 16-byte aligned outputs).  Returns hipError_t.
+hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream);
+
+} // namespace tsvpp

@@ -1,0 +1,177 @@
+"""Python host side of the VPP path: enums + FrameParameters mirroring the reference's Python
+surface (tensor_stream/tensor_stream.py:48-136), and `VideoProcessor`, the counterpart of the C++
+class (include/VideoProcessor.h:120-149) that drives the HIP kernels through the C ABI.
+
+PyTorch is plumbing here: it owns device memory and the current stream; all compute is in libtsvpp.so.
+"""
+import ctypes
+from enum import Enum
+
+import torch
+
+from . import _native as N
+
+
+class FourCC(Enum):  # reference tensor_stream/tensor_stream.py:48-62
+    Y800 = 0
+    RGB24 = 1
+    BGR24 = 2
+    NV12 = 3
+    UYVY = 4
+    YUV444 = 5
+    HSV = 6
+
+
+class ResizeType(Enum):  # :67-75
+    NEAREST = 0
+    BILINEAR = 1
+    BICUBIC = 2
+    AREA = 3
+
+
+class Planes(Enum):  # :79-83
+    PLANAR = 0
+    MERGED = 1
+
+
+def _v(x):
+    return x.value if isinstance(x, Enum) else int(x)
+
+
+class FrameParameters:
+    """Same constructor as the reference's FrameParameters (tensor_stream/tensor_stream.py:101-136).
+    normalization=None keeps the C++ default: False, except True for HSV (include/VideoProcessor.h:40-47)."""
+
+    def __init__(self, width=0, height=0, crop_coords=(0, 0, 0, 0), resize_type=ResizeType.NEAREST,
+                 pixel_format=FourCC.RGB24, planes_pos=Planes.MERGED, normalization=None):
+        if normalization is None:
+            normalization = _v(pixel_format) == FourCC.HSV.value
+        self.parameters = N.Params(int(crop_coords[0]), int(crop_coords[1]), int(crop_coords[2]), int(crop_coords[3]),
+                                   int(width), int(height), _v(resize_type), _v(pixel_format), _v(planes_pos),
+                                   int(bool(normalization)))
+
+    def __repr__(self):
+        p = self.parameters
+        return (f"FrameParameters(width={p.dst_width}, height={p.dst_height}, "
+                f"crop=({p.crop_left},{p.crop_top},{p.crop_right},{p.crop_bottom}), resize_type={p.resize_type}, "
+                f"pixel_format={p.fourcc}, planes_pos={p.planes}, normalization={bool(p.normalization)})")
+
+
+def output_shape(p, out_w, out_h):
+    """Tensor shape of TensorStream::getFrame (reference src/Wrappers/WrapperPython.cpp:317-341)."""
+    ch = N.lib().tsvpp_channels(p.fourcc)
+    if p.fourcc in (FourCC.RGB24.value, FourCC.BGR24.value):
+        return (out_h, out_w, 3) if p.planes == Planes.MERGED.value else (3, out_h, out_w)
+    if p.fourcc in (FourCC.YUV444.value, FourCC.HSV.value):
+        return (out_h, out_w, 3)
+    return (1, int(out_h * ch), out_w)
+
+
+class VideoProcessor:
+    """Counterpart of the reference's `VideoProcessor` (Init / Convert / Close), with
+    caller-visible torch tensors instead of AVFrame::opaque.
+
+    Convert() takes the NV12 planes as uint8 CUDA tensors (2-D: rows x pitch) and returns a new
+    tensor, or fills `out`.  Work is enqueued on torch's current stream unless a consumer name is
+    given, in which case that consumer's pooled stream is used (reference src/VideoProcessor.cpp:98-104)
+    after making it wait for the current stream.
+    """
+
+    def __init__(self, device=None, max_consumers=5):
+        self._ctx = ctypes.c_void_p()
+        self._lib = N.lib()  # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("VideoProcessor needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        N.check(self._lib.tsvpp_create(self.device, int(max_consumers), ctypes.byref(self._ctx)))
+
+    # reference naming
+    def Close(self):
+        if self._ctx:
+            self._lib.tsvpp_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    close = Close
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+    def out_dims(self, params, in_w, in_h):
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        w, h = ctypes.c_int(0), ctypes.c_int(0)
+        N.check(self._lib.tsvpp_out_dims(ctypes.byref(p), in_w, in_h, ctypes.byref(w), ctypes.byref(h)))
+        return w.value, h.value
+
+    def prepare(self, params, in_w, in_h):
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        N.check(self._lib.tsvpp_prepare(self._ctx, ctypes.byref(p), in_w, in_h))
+
+    def consumer_stream(self, name):
+        s = ctypes.c_void_p()
+        N.check(self._lib.tsvpp_consumer_stream(self._ctx, name.encode(), ctypes.byref(s)))
+        return s.value or 0
+
+    def _alloc(self, p, in_w, in_h, n=None):
+        ow, oh = self.out_dims(p, in_w, in_h)
+        shape = output_shape(p, ow, oh)
+        dtype = torch.float32 if p.normalization else torch.uint8
+        if n is not None:
+            shape = (n,) + tuple(shape)
+        return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+    @staticmethod
+    def _frame(y, uv, width, height):
+        assert y.is_cuda and uv.is_cuda and y.dtype == torch.uint8 and uv.dtype == torch.uint8
+        assert y.dim() == 2 and uv.dim() == 2 and y.stride(1) == 1 and uv.stride(1) == 1
+        h = y.shape[0] if height is None else height
+        w = y.shape[1] if width is None else width
+        return N.NV12(y.data_ptr(), uv.data_ptr(), y.stride(0), uv.stride(0), w, h)
+
+    def Convert(self, y, uv, params, out=None, width=None, height=None, consumer=None):
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        fr = self._frame(y, uv, width, height)
+        if out is None:
+            out = self._alloc(p, fr.width, fr.height)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if consumer is not None:
+            stream = self._on_consumer_stream(consumer)
+        N.check(self._lib.tsvpp_convert(self._ctx, ctypes.byref(fr), ctypes.byref(p), out.data_ptr(), stream))
+        return out
+
+    convert = Convert
+
+    def convert_batch(self, ys, uvs, params, out=None, width=None, height=None):
+        """ys / uvs: 3-D uint8 tensors (n, rows, pitch) or lists of 2-D tensors; one launch per 64 frames."""
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        n = len(ys)
+        frames = (N.NV12 * n)(*[self._frame(ys[i], uvs[i], width, height) for i in range(n)])
+        if out is None:
+            out = self._alloc(p, frames[0].width, frames[0].height, n)
+        outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.tsvpp_convert_batch(self._ctx, n, frames, ctypes.byref(p), outs, stream))
+        return out
+
+    def _on_consumer_stream(self, name):
+        raw = self.consumer_stream(name)
+        ext = torch.cuda.ExternalStream(raw, device=self.device)
+        ext.wait_stream(torch.cuda.current_stream(self.device))
+        return raw
+
+    def get_coeffs(self):
+        c = N.Coeffs()
+        N.check(self._lib.tsvpp_get_coeffs(self._ctx, ctypes.byref(c)))
+        return [getattr(c, f[0]) for f in N.Coeffs._fields_]
+
+    def set_coeffs(self, values):
+        c = N.Coeffs(*[float(v) for v in values])
+        N.check(self._lib.tsvpp_set_coeffs(self._ctx, ctypes.byref(c)))
+
+
+def default_coeffs():
+    c = N.Coeffs()
+    N.lib().tsvpp_default_coeffs(ctypes.byref(c))
+    return [getattr(c, f[0]) for f in N.Coeffs._fields_]

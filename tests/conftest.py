@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tensor-stream_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """The reference's own fp32 golden files (tests/golden/make_golden.py) + the recovered NV12 input."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_320x240.npz"))
+    g = {k: z[k] for k in z.files}
+    nv = g["input_nv12_u8"]
+    g["Y"] = nv[: 320 * 240].reshape(240, 320).copy()
+    g["UVp"] = nv[320 * 240:].reshape(120, 320).copy()
+    return g
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def vpp():
+    """HIP VideoProcessor on cuda:0 (gpu tests only).  No fallback: a missing library is an error."""
+    import torch
+    assert torch.cuda.is_available(), "gpu test on a box without a GPU"
+    import tensor_stream
+    v = tensor_stream.VideoProcessor(device=0, max_consumers=5)
+    yield v
+    v.Close()

@@ -1,0 +1,195 @@
+"""GPU: the fused HIP path (through the C ABI) against the CPU oracle and the reference's goldens.
+
+Bar: bit-exact for uint8 output; 0 ULP for the fp32-normalised output (north_star allows 1).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import coverage_frame, synth_nv12, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+RGB24, BGR24 = 1, 2
+PLANAR, MERGED = 0, 1
+NEAREST, BILINEAR, BICUBIC, AREA = 0, 1, 2, 3
+
+
+def run_hip(vpp, y, uv, width=None, **kw):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=kw.get("dst", (0, 0))[0], height=kw.get("dst", (0, 0))[1],
+                            crop_coords=kw.get("crop", (0, 0, 0, 0)), resize_type=kw.get("resize_type", 0),
+                            pixel_format=kw.get("fourcc", RGB24), planes_pos=kw.get("planes", MERGED),
+                            normalization=kw.get("normalization", False))
+    ty = torch.from_numpy(y).cuda()
+    tuv = torch.from_numpy(uv).cuda()
+    out = vpp.Convert(ty, tuv, fp, width=width)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def check(vpp, oracle, y, uv, width=None, **kw):
+    got = run_hip(vpp, y, uv, width=width, **kw)
+    ref, ow, oh = oracle.convert(y, uv, crop=kw.get("crop", (0, 0, 0, 0)), dst=kw.get("dst", (0, 0)),
+                                 resize_type=kw.get("resize_type", 0), fourcc=kw.get("fourcc", RGB24),
+                                 planes=kw.get("planes", MERGED), normalization=kw.get("normalization", False),
+                                 nthreads=8, width=width)
+    assert got.shape == oracle.shape_for(kw.get("fourcc", RGB24), kw.get("planes", MERGED), ow, oh)
+    got = got.ravel()
+    assert got.dtype == ref.dtype and got.size == ref.size
+    if got.dtype == np.uint8:
+        bad = int((got != ref).sum())
+        assert bad == 0, f"{bad} of {got.size} bytes differ from the oracle ({kw})"
+    else:
+        assert ulp_diff(got, ref) == 0, f"fp32 output differs from the oracle by {ulp_diff(got, ref)} ulp ({kw})"
+    return got
+
+
+@pytest.mark.parametrize("fourcc,name", [(RGB24, "RGB24"), (BGR24, "BGR24")])
+def test_reference_golden_files_bit_exact(vpp, golden, fourcc, name):
+    """NV12 -> RGB24/BGR24 MERGED fp32 of the reference's own 320x240 frame == its golden dump
+    (reference tests/src/VPPTests.cpp:338-384)."""
+    got = run_hip(vpp, golden["Y"], golden["UVp"], fourcc=fourcc, planes=MERGED, normalization=True)
+    assert got.shape == (240, 320, 3) and got.dtype == np.float32
+    assert np.array_equal(got.ravel().view(np.uint32), golden[name])
+
+
+@pytest.mark.parametrize("fourcc", [RGB24, BGR24])
+@pytest.mark.parametrize("planes", [PLANAR, MERGED])
+@pytest.mark.parametrize("norm", [False, True])
+def test_colour_only_all_layouts(vpp, oracle, golden, fourcc, planes, norm):
+    check(vpp, oracle, golden["Y"], golden["UVp"], fourcc=fourcc, planes=planes, normalization=norm)
+
+
+def test_all_2pow24_yuv_triples(vpp, oracle):
+    """Every (Y,U,V) input through the colour stage, u8 and fp32 (covers clamps, sub-16 luma, x/255)."""
+    y, uv = coverage_frame()
+    check(vpp, oracle, y, uv, fourcc=RGB24, planes=PLANAR, normalization=False)
+    got = check(vpp, oracle, y, uv, fourcc=BGR24, planes=MERGED, normalization=True)
+    # x/255 sequence hits all 256 quotients
+    assert np.unique(got).size == 256
+
+
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+@pytest.mark.parametrize("src,dst", [((1920, 1080), (1280, 720)),   # headline, ratio 1.5
+                                     ((1080, 608), (480, 360)),     # reference test size, non-dyadic
+                                     ((1080, 608), (540, 304)),     # exact 2x
+                                     ((640, 360), (1280, 720)),     # 2x up-scale (AREA -> bilinear variant)
+                                     ((320, 240), (358, 202)),      # odd-ish ratios, dst_w % 4 != 0
+                                     ((642, 362), (214, 182))])     # ratio 3 x 1.989, src_w % 4 != 0
+def test_resize_types_bit_exact(vpp, oracle, rt, src, dst):
+    y, uv = synth_nv12(src[0], src[1], seed=rt * 100 + src[0])
+    check(vpp, oracle, y, uv, dst=dst, resize_type=rt, fourcc=RGB24, planes=MERGED, normalization=False)
+
+
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+def test_resize_fp32_planar_bgr(vpp, oracle, rt):
+    y, uv = synth_nv12(1080, 608, seed=7 + rt)
+    check(vpp, oracle, y, uv, dst=(720, 404), resize_type=rt, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+@pytest.mark.parametrize("crop", [(0, 0, 1280, 720), (120, 64, 600, 400), (121, 65, 601, 401), (1, 0, 321, 200),
+                                  (480, 340, 1080, 608)])
+def test_crop_only_including_odd_origin(vpp, oracle, crop):
+    """Crop is pointer arithmetic in the fused kernel; an odd left/top reproduces the reference's
+    chroma quirk (src/Crop.cu:10-13)."""
+    y, uv = synth_nv12(1920 if crop[2] > 1080 else 1080, 1080 if crop[2] > 1080 else 608, seed=crop[0] + 3)
+    check(vpp, oracle, y, uv, crop=crop, fourcc=RGB24, planes=MERGED)
+    check(vpp, oracle, y, uv, crop=crop, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+def test_crop_plus_resize(vpp, oracle, rt):
+    # reference tests/src/VPPTests.cpp:266-298 shapes: crop then resize
+    y, uv = synth_nv12(1080, 608, seed=11 + rt)
+    check(vpp, oracle, y, uv, crop=(480, 340, 1080, 608), dst=(480, 320), resize_type=rt, planes=PLANAR)
+    check(vpp, oracle, y, uv, crop=(121, 65, 601, 401), dst=(300, 200), resize_type=rt, planes=MERGED, normalization=True)
+
+
+def test_crop_ignored_unless_strictly_smaller_in_both_dims(vpp, oracle):
+    y, uv = synth_nv12(640, 360, seed=5)
+    got = check(vpp, oracle, y, uv, crop=(0, 0, 640, 200))  # same width -> no crop (src/VideoProcessor.cpp:109)
+    assert got.size == 640 * 360 * 3
+
+
+def test_resize_to_same_size_is_no_resize(vpp, oracle):
+    y, uv = synth_nv12(640, 360, seed=6)
+    check(vpp, oracle, y, uv, dst=(640, 360), resize_type=BICUBIC)
+
+
+@pytest.mark.parametrize("pitch", [2048, 1984])
+def test_padded_pitch(vpp, oracle, pitch):
+    """Decoder surfaces have pitch > width (linesize aligned to 256/512 B)."""
+    y, uv = synth_nv12(1920, 1080, seed=9, pitch=pitch)
+    check(vpp, oracle, y, uv, width=1920, fourcc=BGR24, planes=PLANAR, normalization=True)
+    check(vpp, oracle, y, uv, width=1920, dst=(1280, 720), resize_type=BILINEAR, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+# ---- BASELINE.json configs (C2..C5 + headline), full size, against the oracle ----
+def test_config_C2_1080p_bgr_planar_fp32(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=2)
+    check(vpp, oracle, y, uv, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+def test_config_C3_crop_bilinear_256(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=3)
+    check(vpp, oracle, y, uv, crop=(0, 0, 1280, 720), dst=(256, 256), resize_type=BILINEAR, fourcc=RGB24, planes=PLANAR, normalization=True)
+
+
+def test_config_C4_4k_bicubic_merged_u8(vpp, oracle):
+    y, uv = synth_nv12(3840, 2160, seed=4)
+    check(vpp, oracle, y, uv, dst=(1280, 720), resize_type=BICUBIC, fourcc=BGR24, planes=MERGED, normalization=False)
+
+
+def test_config_C5_4k_area_planar_fp32(vpp, oracle):
+    y, uv = synth_nv12(3840, 2160, seed=5)
+    check(vpp, oracle, y, uv, dst=(640, 360), resize_type=AREA, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+def test_headline_1080p_to_720p_bgr_planar_fp32(vpp, oracle, rt):
+    y, uv = synth_nv12(1920, 1080, seed=20 + rt)
+    check(vpp, oracle, y, uv, dst=(1280, 720), resize_type=rt, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
+def test_batch_equals_single_frames(vpp, oracle):
+    """tsvpp_convert_batch (one launch, 70 frames -> two launches) == per-frame conversions."""
+    import tensor_stream as ts
+    n = 70
+    frames = [synth_nv12(640, 360, seed=100 + i) for i in range(n)]
+    ys = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    uvs = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    fp = ts.FrameParameters(width=320, height=180, resize_type=BILINEAR, pixel_format=BGR24, planes_pos=PLANAR, normalization=True)
+    out = vpp.convert_batch(ys, uvs, fp)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert out.shape == (n, 3, 180, 320)
+    for i in (0, 1, 63, 64, 69):
+        ref, _, _ = oracle.convert(frames[i][0], frames[i][1], dst=(320, 180), resize_type=BILINEAR, fourcc=BGR24,
+                                   planes=PLANAR, normalization=True)
+        assert ulp_diff(out[i].ravel(), ref) == 0
+
+
+def test_errors(vpp):
+    import tensor_stream as ts
+    y = torch.zeros((360, 640), dtype=torch.uint8, device="cuda")
+    uv = torch.zeros((180, 640), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="-2"):
+        vpp.Convert(y, uv, ts.FrameParameters(width=321, height=181))  # odd output size
+    with pytest.raises(RuntimeError, match="-2"):
+        vpp.Convert(y, uv, ts.FrameParameters(width=320, height=180, resize_type=7))
+    with pytest.raises(RuntimeError, match="-3"):
+        vpp.Convert(y, uv, ts.FrameParameters(crop_coords=(600, 0, 700, 100)))  # crop box outside the frame
+
+
+def test_consumer_pool_semantics(vpp):
+    """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
+    (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
+    import tensor_stream as ts
+    v = ts.VideoProcessor(device=0, max_consumers=2)
+    a = v.consumer_stream("a")
+    b = v.consumer_stream("b")
+    assert a != b and v.consumer_stream("a") == a
+    with pytest.raises(RuntimeError, match="-3"):
+        v.consumer_stream("c")
+    v.Close()
