@@ -9,6 +9,10 @@ import subprocess
 
 import numpy as np
 
+# libgomp workers must sleep, not spin, between parallel regions: spinning threads starve the HIP
+# runtime's completion thread of the process that also drives the GPU (bench.py, GPU tests).
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvpp_oracle.so")
 
@@ -60,6 +64,21 @@ def out_dims(w, h, crop=(0, 0, 0, 0), dst=(0, 0)):
     if dst[0] and dst[1]:
         ow, oh = dst
     return ow, oh
+
+
+def host_cores():
+    """Cores this process may actually use: CPU affinity, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def convert(y, uv, crop=(0, 0, 0, 0), dst=(0, 0), resize_type=NEAREST, fourcc=RGB24,

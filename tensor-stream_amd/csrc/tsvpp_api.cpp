@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -85,6 +86,9 @@ struct tsvpp_ctx {
     std::mutex stream_mu;
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
+    int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
+    int nt_stores = 0, no_xcd_remap = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_NO_XCD, TSVPP_SHAPE=tx,ty
+    int ablate = 0;
     std::mutex area_mu;
 };
 
@@ -203,6 +207,11 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     tsvpp_ctx *ctx = new tsvpp_ctx();
     ctx->device = device;
     tsvpp_default_coeffs(&ctx->coeffs);
+    if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
+    if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = (e[0] == '1');
+    if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_NO_XCD")) ctx->no_xcd_remap = (e[0] == '1');
+    if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
     for (int i = 0; i < max_consumers; i++) {
         hipStream_t s = nullptr;
         e = hipStreamCreate(&s); // blocking stream, as the reference (src/VideoProcessor.cpp:86)
@@ -314,6 +323,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.yr = pl.yr;
     d.swap_rb = pl.swap_rb;
     d.k = ctx->coeffs;
+    d.force_gather = ctx->force_gather;
+    d.nt_stores = ctx->nt_stores;
+    d.no_xcd_remap = ctx->no_xcd_remap;
+    d.shape_tx = ctx->shape_tx;
+    d.shape_ty = ctx->shape_ty;
+    d.ablate = ctx->ablate;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;
         sts = get_area_table(ctx, pl.xr, tx);

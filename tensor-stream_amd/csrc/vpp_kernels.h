@@ -33,9 +33,20 @@ struct LaunchDesc {
     // AREA-down weight tables: nx rows of rx floats, ny rows of ry floats (rx = ceil(xr))
     const float *patx, *paty;
     int nx, ny, rx, ry;
-    // grid decomposition
+    // grid decomposition (filled by launch_fused)
     int tiles_x, tiles_y, n_frames;
     int blocks_per_xcd; // ceil(total_tiles / 8)
+    int tx, ty, tx_shift; // workgroup = tx x ty thread tiles of 4 x 2 output pixels
+    // LDS staging bounds (staged kernel): max source bytes per row, rows, 16-byte chunks per row
+    int lds_span_y, lds_rows_y, lds_cpr_y;
+    int lds_span_uv, lds_rows_uv, lds_cpr_uv;
+    int lds_slot_y, lds_slot_uv; // log2 of the lanes serving one staged row
+    int force_gather; // debugging / A-B: 1 = always use the global-gather kernel
+    // tuning knobs (ctx options / TSVPP_* environment, see tsvpp_api.cpp)
+    int nt_stores;    // 1 = non-temporal output stores
+    int no_xcd_remap; // 1 = workgroup id -> tile in plain raster order
+    int shape_tx, shape_ty; // != 0: force the workgroup shape
+    int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
 };
 
 // Output flavour: element type x layout.

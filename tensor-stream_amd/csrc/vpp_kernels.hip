@@ -20,31 +20,59 @@
 namespace tsvpp {
 
 // Thread tile: 2 output rows x 4 output columns (= one resized-chroma row of 2 pairs).
-// Workgroup: 256 threads as 32 x 8 thread tiles -> 128 x 16 output pixels.
-constexpr int TX = 32, TY = 8, PXW = 4, PXH = 2;
-constexpr int TILE_W = TX * PXW, TILE_H = TY * PXH;
+// Workgroup: tx x ty thread tiles (launch-time choice, tx a power of two, tx*ty <= 256), i.e.
+// (4*tx) x (2*ty) output pixels; 32 x 8 threads -> 128 x 16 pixels is the default.
+constexpr int PXW = 4, PXH = 2;
+constexpr int MAX_THREADS = 256;
 constexpr int NUM_XCD = 8;
 
+// Two floats per lane: gfx950 executes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on such pairs in
+// the time of one scalar op, and each half is an independent IEEE operation -- results are
+// bit-identical to the scalar sequence.  The VPP kernels are VALU-issue bound before they are
+// HBM bound, so the blend and colour arithmetic is written on horizontally adjacent pixel pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // ----------------------------------------------------------------------------------------------
-// Source access.  Coordinates are clamped into the logical source so that no input, however odd,
-// can fault; for every valid (even-sized) request the clamps never fire.
-struct Src {
+// Source access.  Two readers with the same interface:
+//   GlobalSrc -- byte gathers straight from global memory (fallback: huge footprints, odd widths).
+//                Coordinates are clamped into the logical source so that no input can fault; for
+//                every valid (even-sized) request the clamps never fire.
+//   LdsSrc    -- the workgroup's source footprint staged in LDS by 16-byte coalesced loads.
+struct GlobalSrc {
     const uint8_t *y, *uv;
     int py, puv; // pitches in bytes
     int w, h;    // logical source size in luma pixels
+    __device__ __forceinline__ int Y(int row, int col) const {
+        row = min(max(row, 0), h - 1);
+        col = min(max(col, 0), w - 1);
+        return y[(uint32_t)row * (uint32_t)py + (uint32_t)col];
+    }
+    // col is a BYTE column of the interleaved UV plane
+    __device__ __forceinline__ int UV(int row, int col) const {
+        row = min(max(row, 0), (h >> 1) - 1);
+        col = min(max(col, 0), w - 1);
+        return uv[(uint32_t)row * (uint32_t)puv + (uint32_t)col];
+    }
 };
 
-__device__ __forceinline__ int ld_y(const Src &s, int row, int col) {
-    row = min(max(row, 0), s.h - 1);
-    col = min(max(col, 0), s.w - 1);
-    return s.y[(uint32_t)row * (uint32_t)s.py + (uint32_t)col];
-}
-// col is a BYTE column of the interleaved UV plane
-__device__ __forceinline__ int ld_uv(const Src &s, int row, int col) {
-    row = min(max(row, 0), (s.h >> 1) - 1);
-    col = min(max(col, 0), s.w - 1);
-    return s.uv[(uint32_t)row * (uint32_t)s.puv + (uint32_t)col];
-}
+// One staged plane: LDS row r holds source row (y0 + r); because global loads are 16-byte aligned
+// and the pitch need not be, each row is shifted by its own misalignment (m0 + r*pm) & 15.
+struct LdsPlane {
+    const uint8_t *base;
+    int x0, y0; // source byte-column / row of the footprint origin
+    int lp;     // LDS row pitch in bytes (multiple of 16)
+    int m0, pm; // misalignment of row 0, pitch & 15
+    __device__ __forceinline__ int at(int row, int col) const {
+        const int r = row - y0;
+        return base[r * lp + ((m0 + r * pm) & 15) + (col - x0)];
+    }
+};
+struct LdsSrc {
+    LdsPlane py_, puv_;
+    int w, h;
+    __device__ __forceinline__ int Y(int row, int col) const { return py_.at(row, col); }
+    __device__ __forceinline__ int UV(int row, int col) const { return puv_.at(row, col); }
+};
 
 // ----------------------------------------------------------------------------------------------
 // Bilinear blend, reference src/Resize.cu:17-23: four products summed left to right, truncated.
@@ -121,13 +149,13 @@ __device__ __forceinline__ void bicubic_offsets(int p, int step, int limit, int 
 // The chroma grid reuses the luma formulas on its own indices (the reference runs the same
 // thread for both, guarded by i < H/2 && j < W/2).
 
-template <int MODE>
-__device__ __forceinline__ int sample_luma(const Src &s, const LaunchDesc &d, int i, int j) {
+template <int MODE, class S>
+__device__ __forceinline__ int sample_luma(const S &s, const LaunchDesc &d, int i, int j) {
     if constexpr (MODE == M_NONE) {
-        return ld_y(s, i, j);
+        return s.Y(i, j);
     } else if constexpr (MODE == M_NEAREST) { // src/Resize.cu:249-258
         int y = (int)(d.yr * (float)i), x = (int)(d.xr * (float)j);
-        return ld_y(s, y, x);
+        return s.Y(y, x);
     } else if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         int x, y;
         float wx, wy;
@@ -140,7 +168,7 @@ __device__ __forceinline__ int sample_luma(const Src &s, const LaunchDesc &d, in
         }
         int xd = (x + 1 >= s.w) ? 0 : 1;
         int y2 = (y + 1 >= s.h) ? y : y + 1;
-        return bilerp(ld_y(s, y, x), ld_y(s, y, x + xd), ld_y(s, y2, x), ld_y(s, y2, x + xd), wx, wy) & 0xff;
+        return bilerp(s.Y(y, x), s.Y(y, x + xd), s.Y(y2, x), s.Y(y2, x + xd), wx, wy) & 0xff;
     } else if constexpr (MODE == M_BICUBIC) {
         int x, y;
         double wx, wy;
@@ -156,7 +184,7 @@ __device__ __forceinline__ int sample_luma(const Src &s, const LaunchDesc &d, in
         int b[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            b[r] = cubic4(cx, ld_y(s, rows[r], x - xl), ld_y(s, rows[r], x), ld_y(s, rows[r], x + xh), ld_y(s, rows[r], x + 2 * xh));
+            b[r] = cubic4(cx, s.Y(rows[r], x - xl), s.Y(rows[r], x), s.Y(rows[r], x + xh), s.Y(rows[r], x + 2 * xh));
         return cubic4(cy, b[0], b[1], b[2], b[3]);
     } else { // M_AREA_DOWN, src/Resize.cu:160-178, 186-201
         int y = (int)(d.yr * (float)i), x = (int)(d.xr * (float)j);
@@ -168,7 +196,7 @@ __device__ __forceinline__ int sample_luma(const Src &s, const LaunchDesc &d, in
             for (int b = 0; b < d.rx; b++) {
                 float wgt = px[b] * wy;
                 div = div + wgt;
-                float v = (float)ld_y(s, y + a, x + b) * wgt;
+                float v = (float)s.Y(y + a, x + b) * wgt;
                 sum = sum + v;
             }
         }
@@ -177,16 +205,16 @@ __device__ __forceinline__ int sample_luma(const Src &s, const LaunchDesc &d, in
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ void sample_chroma(const Src &s, const LaunchDesc &d, int ci, int cj, int &U, int &V) {
+template <int MODE, class S>
+__device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, int ci, int cj, int &U, int &V) {
     const int ch = s.h >> 1; // rows of the UV plane
     if constexpr (MODE == M_NONE) {
-        U = ld_uv(s, ci, 2 * cj);
-        V = ld_uv(s, ci, 2 * cj + 1);
+        U = s.UV(ci, 2 * cj);
+        V = s.UV(ci, 2 * cj + 1);
     } else if constexpr (MODE == M_NEAREST) { // src/Resize.cu:262-265
         int y = (int)(d.yr * (float)ci), x = (int)(d.xr * (float)cj);
-        U = ld_uv(s, y, 2 * x);
-        V = ld_uv(s, y, 2 * x + 1);
+        U = s.UV(y, 2 * x);
+        V = s.UV(y, 2 * x + 1);
     } else if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) { // src/Resize.cu:308-309, 236-237
         int x, y;
         float wx, wy;
@@ -201,8 +229,8 @@ __device__ __forceinline__ void sample_chroma(const Src &s, const LaunchDesc &d,
         int du = (xu + 2 >= s.w) ? 0 : 2;
         int dv = (xv + 2 >= s.w) ? 0 : 2;
         int y2 = (y + 1 >= ch) ? y : y + 1;
-        U = bilerp(ld_uv(s, y, xu), ld_uv(s, y, xu + du), ld_uv(s, y2, xu), ld_uv(s, y2, xu + du), wx, wy) & 0xff;
-        V = bilerp(ld_uv(s, y, xv), ld_uv(s, y, xv + dv), ld_uv(s, y2, xv), ld_uv(s, y2, xv + dv), wx, wy) & 0xff;
+        U = bilerp(s.UV(y, xu), s.UV(y, xu + du), s.UV(y2, xu), s.UV(y2, xu + du), wx, wy) & 0xff;
+        V = bilerp(s.UV(y, xv), s.UV(y, xv + dv), s.UV(y2, xv), s.UV(y2, xv + dv), wx, wy) & 0xff;
     } else if constexpr (MODE == M_BICUBIC) { // src/Resize.cu:353-354
         int x, y;
         double wx, wy;
@@ -221,7 +249,7 @@ __device__ __forceinline__ void sample_chroma(const Src &s, const LaunchDesc &d,
             int b[4];
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                b[r] = cubic4(cx, ld_uv(s, rows[r], xc - xl), ld_uv(s, rows[r], xc), ld_uv(s, rows[r], xc + xh), ld_uv(s, rows[r], xc + 2 * xh));
+                b[r] = cubic4(cx, s.UV(rows[r], xc - xl), s.UV(rows[r], xc), s.UV(rows[r], xc + xh), s.UV(rows[r], xc + 2 * xh));
             int v = cubic4(cy, b[0], b[1], b[2], b[3]);
             if (comp == 0) U = v; else V = v;
         }
@@ -235,8 +263,8 @@ __device__ __forceinline__ void sample_chroma(const Src &s, const LaunchDesc &d,
             for (int b = 0; b < d.rx; b++) {
                 float wgt = px[b] * wy;
                 div = div + wgt;
-                float vu = (float)ld_uv(s, y + a, 2 * x + 2 * b) * wgt;
-                float vv = (float)ld_uv(s, y + a, 2 * x + 2 * b + 1) * wgt;
+                float vu = (float)s.UV(y + a, 2 * x + 2 * b) * wgt;
+                float vv = (float)s.UV(y + a, 2 * x + 2 * b + 1) * wgt;
                 su = su + vu;
                 sv = sv + vv;
             }
@@ -249,178 +277,620 @@ __device__ __forceinline__ void sample_chroma(const Src &s, const LaunchDesc &d,
 }
 
 // ----------------------------------------------------------------------------------------------
-// BT.601 limited-range YUV -> RGB, reference src/ColorConversion.cu:23-38.
-__device__ __forceinline__ void yuv2rgb(int Y, int U, int V, const tsvpp_coeffs &k, int &R, int &G, int &B) {
-    float yv = fmaxf(0.f, (float)Y - k.y_offset) * k.y_scale;
-    float fu = (float)U - k.c_offset, fv = (float)V - k.c_offset;
-    float rv = k.v_to_r * fv;
-    rv = rv + k.round_bias;
-    float bv = k.u_to_b * fu;
-    bv = bv + k.round_bias;
-    float g1 = k.v_to_g * fv;
-    float g2 = k.u_to_g * fu; // u_to_g is negative: g1 + g2 == g1 - |u_to_g|*fu exactly
-    float gv = g1 + g2;
-    gv = gv + k.round_bias;
-    R = clamp255((int)(yv + rv));
-    B = clamp255((int)(yv + bv));
-    G = clamp255((int)(yv + gv));
-}
-
-// v / 255 for an integer v in [0, 255], correctly rounded (== IEEE division, verified for all
-// 256 inputs in tests): reciprocal multiply + one explicit-FMA Newton correction, 3 VALU ops
-// instead of the ~10-instruction v_div_scale/fmas/fixup sequence.
-__device__ __forceinline__ float norm255(int v) {
-    const float r = 1.0f / 255.0f;
-    float f = (float)v;
-    float q = f * r;
-    float e = __builtin_fmaf(-q, 255.0f, f);
-    return __builtin_fmaf(e, r, q);
-}
+// Colour back end shared by every kernel.  Inputs are the resized samples as integer-valued floats:
+// luma Yf[2][4] and one (U, V) pair per 2x2 block.  BT.601 limited range, reference
+// src/ColorConversion.cu:23-38:
+//     Yv = max(0, Y - 16) * 1.164;  R = (int)(Yv + (1.596 (V-128) + 0.5)) ... min 255, max 0.
+// (int)x truncates toward zero == trunc(x); the clamp is done on the truncated float.
 
 template <int OUT> struct OutT { using type = uint8_t; };
 template <> struct OutT<O_F32_PLANAR> { using type = float; };
 template <> struct OutT<O_F32_MERGED> { using type = float; };
 
-__device__ __forceinline__ float cvt_out(int v, float *) { return norm255(v); }
-__device__ __forceinline__ uint8_t cvt_out(int v, uint8_t *) { return (uint8_t)v; }
+// Per-block chroma terms: t0 / t2 are added to luma for the first / third stored channel
+// (R,B or B,R when swapped), tg for green.
+__device__ __forceinline__ void chroma_terms(float Uf, float Vf, const tsvpp_coeffs &k, int swap_rb, float &t0, float &tg, float &t2) {
+    f2 uv = { Uf, Vf };
+    uv = uv - (f2){ k.c_offset, k.c_offset };
+    f2 br = uv * (f2){ k.u_to_b, k.v_to_r };
+    br = br + (f2){ k.round_bias, k.round_bias }; // { 2.018 (U-128) + .5, 1.596 (V-128) + .5 }
+    f2 g = uv * (f2){ k.u_to_g, k.v_to_g };        // u_to_g < 0: g.y + g.x == -0.813 (V-128) - 0.391 (U-128)
+    float gv = g.y + g.x;
+    tg = gv + k.round_bias;
+    t0 = swap_rb ? br.x : br.y;
+    t2 = swap_rb ? br.y : br.x;
+}
 
-// ----------------------------------------------------------------------------------------------
-template <int MODE, int OUT, bool VEC>
-__global__ __launch_bounds__(TX * TY) void vpp_fused_kernel(const LaunchDesc d, const FrameTable t) {
+__device__ __forceinline__ f2 trunc_clamp255(f2 v) {
+    f2 r;
+    r.x = __builtin_amdgcn_fmed3f(__builtin_truncf(v.x), 0.0f, 255.0f);
+    r.y = __builtin_amdgcn_fmed3f(__builtin_truncf(v.y), 0.0f, 255.0f);
+    return r;
+}
+
+// v / 255 for an integer-valued v in [0, 255], correctly rounded (== the reference's IEEE
+// `/= 255`; all 256 inputs are checked by the tests): 1/255 = hi + lo, e = v*lo, q = fma(v, hi, e).
+// Two (packed) VALU ops instead of the ~10-instruction v_div_scale/fmas/fixup sequence; a zero of
+// either sign yields +0.0 like the reference's int -> float conversion.
+__device__ __forceinline__ f2 norm255(f2 v) {
+    const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;
+    f2 e = v * (f2){ lo, lo };
+    f2 q;
+    q.x = __builtin_fmaf(v.x, hi, e.x);
+    q.y = __builtin_fmaf(v.y, hi, e.y);
+    return q;
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float e, int nt) {
+    vf4 v = { a, b, c, e };
+    if (nt) __builtin_nontemporal_store(v, (vf4 *)p);
+    else *(vf4 *)p = v;
+}
+
+// One output row of this thread: 4 pixels -> 3 channels, converted and stored.
+template <int OUT, bool VEC>
+__device__ __forceinline__ void color_store_row(const float Yf[PXW], const float t0[2], const float tg[2], const float t2[2],
+                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, size_t pix, size_t plane, int ncol, int nt) {
     using T = typename OutT<OUT>::type;
     constexpr bool PLANAR = (OUT == O_U8_PLANAR || OUT == O_F32_PLANAR);
+    f2 c0[2], c1[2], c2[2]; // channel values of pixel pairs (0,1) and (2,3)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        f2 y = { Yf[2 * p], Yf[2 * p + 1] };
+        y = y - (f2){ k.y_offset, k.y_offset };
+        y.x = __builtin_fmaxf(0.0f, y.x);
+        y.y = __builtin_fmaxf(0.0f, y.y);
+        y = y * (f2){ k.y_scale, k.y_scale };
+        c0[p] = trunc_clamp255(y + (f2){ t0[p], t0[p] });
+        c1[p] = trunc_clamp255(y + (f2){ tg[p], tg[p] });
+        c2[p] = trunc_clamp255(y + (f2){ t2[p], t2[p] });
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            c0[p] = norm255(c0[p]);
+            c1[p] = norm255(c1[p]);
+            c2[p] = norm255(c2[p]);
+        }
+        float *o = (float *)out;
+        if constexpr (VEC) {
+            if constexpr (PLANAR) {
+                st4(o + pix, c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
+                st4(o + plane + pix, c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
+                st4(o + 2 * plane + pix, c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
+            } else {
+                float *q = o + 3 * pix;
+                st4(q, c0[0].x, c1[0].x, c2[0].x, c0[0].y, nt);
+                st4(q + 4, c1[0].y, c2[0].y, c0[1].x, c1[1].x, nt);
+                st4(q + 8, c2[1].x, c0[1].y, c1[1].y, c2[1].y, nt);
+            }
+        } else {
+            const float v0[4] = { c0[0].x, c0[0].y, c0[1].x, c0[1].y }, v1[4] = { c1[0].x, c1[0].y, c1[1].x, c1[1].y },
+                        v2[4] = { c2[0].x, c2[0].y, c2[1].x, c2[1].y };
+            for (int c = 0; c < ncol; c++) {
+                if constexpr (PLANAR) {
+                    o[pix + c] = v0[c];
+                    o[plane + pix + c] = v1[c];
+                    o[2 * plane + pix + c] = v2[c];
+                } else {
+                    o[3 * (pix + c)] = v0[c];
+                    o[3 * (pix + c) + 1] = v1[c];
+                    o[3 * (pix + c) + 2] = v2[c];
+                }
+            }
+        }
+    } else {
+        const uint8_t v0[4] = { (uint8_t)(int)c0[0].x, (uint8_t)(int)c0[0].y, (uint8_t)(int)c0[1].x, (uint8_t)(int)c0[1].y };
+        const uint8_t v1[4] = { (uint8_t)(int)c1[0].x, (uint8_t)(int)c1[0].y, (uint8_t)(int)c1[1].x, (uint8_t)(int)c1[1].y };
+        const uint8_t v2[4] = { (uint8_t)(int)c2[0].x, (uint8_t)(int)c2[0].y, (uint8_t)(int)c2[1].x, (uint8_t)(int)c2[1].y };
+        uint8_t *o = (uint8_t *)out;
+        if constexpr (VEC) {
+            if constexpr (PLANAR) {
+                *(uchar4 *)(o + pix) = make_uchar4(v0[0], v0[1], v0[2], v0[3]);
+                *(uchar4 *)(o + plane + pix) = make_uchar4(v1[0], v1[1], v1[2], v1[3]);
+                *(uchar4 *)(o + 2 * plane + pix) = make_uchar4(v2[0], v2[1], v2[2], v2[3]);
+            } else {
+                uchar4 *q = (uchar4 *)(o + 3 * pix);
+                q[0] = make_uchar4(v0[0], v1[0], v2[0], v0[1]);
+                q[1] = make_uchar4(v1[1], v2[1], v0[2], v1[2]);
+                q[2] = make_uchar4(v2[2], v0[3], v1[3], v2[3]);
+            }
+        } else {
+            for (int c = 0; c < ncol; c++) {
+                if constexpr (PLANAR) {
+                    o[pix + c] = v0[c];
+                    o[plane + pix + c] = v1[c];
+                    o[2 * plane + pix + c] = v2[c];
+                } else {
+                    o[3 * (pix + c)] = v0[c];
+                    o[3 * (pix + c) + 1] = v1[c];
+                    o[3 * (pix + c) + 2] = v2[c];
+                }
+            }
+        }
+    }
+}
 
-    // XCD-aware decomposition: consecutive workgroup ids land on different XCDs (id % 8), so give
-    // every XCD a contiguous run of (frame, tile) work -- neighbouring tiles then share their
-    // source halo rows in ONE L2 instead of fetching them into two.
+// Colour-convert + store a thread tile (2 rows x 4 columns) given its resized samples.
+template <int OUT, bool VEC>
+__device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
+                                                 typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
+    float t0[2], tg[2], t2[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+    const size_t plane = (size_t)d.dst_w * (size_t)d.dst_h;
+#pragma unroll
+    for (int r = 0; r < PXH; r++)
+        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (size_t)(i0 + r) * (size_t)d.dst_w + (size_t)j0, plane, ncol, d.nt_stores);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Work decomposition shared by all kernels.  XCD-aware: consecutive workgroup ids land on
+// different XCDs (id % 8), so every XCD gets a contiguous run of (frame, tile) work and
+// neighbouring tiles share their source halo rows in ONE L2 instead of fetching them into two.
+struct TileId {
+    int frame, tx, ty;
+    bool valid;
+};
+__device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
+    TileId t;
     const int total = d.tiles_x * d.tiles_y * d.n_frames;
-    const int logical = (blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD;
-    if (logical >= total) return;
+    const int logical = d.no_xcd_remap ? (int)blockIdx.x : (int)((blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD);
+    t.valid = logical < total;
     const int tiles = d.tiles_x * d.tiles_y;
-    const int frame = logical / tiles;
-    const int rem = logical - frame * tiles;
-    const int ty = rem / d.tiles_x, tx = rem - ty * d.tiles_x;
+    t.frame = logical / tiles;
+    const int rem = logical - t.frame * tiles;
+    t.ty = rem / d.tiles_x;
+    t.tx = rem - t.ty * d.tiles_x;
+    return t;
+}
 
-    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
-    const int j0 = tx * TILE_W + lx * PXW;
-    const int i0 = ty * TILE_H + ly * PXH;
-    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-
-    Src s;
-    s.y = t.y[frame];
-    s.uv = t.uv[frame];
-    s.py = d.pitch_y;
-    s.puv = d.pitch_uv;
-    s.w = d.src_w;
-    s.h = d.src_h;
-    T *out = (T *)t.out[frame];
-
+// Generic thread tile: samplers (any mode, any reader) -> colour back end.
+template <int MODE, int OUT, bool VEC, class S>
+__device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc &d, typename OutT<OUT>::type *out, int i0, int j0) {
     const int ncol = VEC ? PXW : min(PXW, d.dst_w - j0); // dst_w is even: 2 or 4
     const int ci = i0 >> 1, cj0 = j0 >> 1;
-
-    int U[2], V[2], Y[PXH][PXW];
+    float Uf[2], Vf[2], Yf[PXH][PXW];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        U[c] = V[c] = 0;
-        if (VEC || 2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U[c], V[c]);
+        int U = 128, V = 128;
+        if (VEC || 2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
+        Uf[c] = (float)U;
+        Vf[c] = (float)V;
     }
 #pragma unroll
     for (int r = 0; r < PXH; r++)
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
-            Y[r][c] = 0;
-            if (VEC || c < ncol) Y[r][c] = sample_luma<MODE>(s, d, i0 + r, j0 + c);
+            int Y = 0;
+            if (VEC || c < ncol) Y = sample_luma<MODE>(s, d, i0 + r, j0 + c);
+            Yf[r][c] = (float)Y;
         }
+    color_store_tile<OUT, VEC>(Yf, Uf, Vf, d, out, i0, j0, ncol);
+}
 
-    const size_t plane = (size_t)d.dst_w * (size_t)d.dst_h;
-#pragma unroll
-    for (int r = 0; r < PXH; r++) {
-        T c0[PXW], c1[PXW], c2[PXW];
-#pragma unroll
-        for (int c = 0; c < PXW; c++) {
-            int R, G, B;
-            yuv2rgb(Y[r][c], U[c >> 1], V[c >> 1], d.k, R, G, B);
-            c0[c] = cvt_out(d.swap_rb ? B : R, (T *)nullptr);
-            c1[c] = cvt_out(G, (T *)nullptr);
-            c2[c] = cvt_out(d.swap_rb ? R : B, (T *)nullptr);
-        }
-        const size_t pix = (size_t)(i0 + r) * (size_t)d.dst_w + (size_t)j0;
-        if constexpr (PLANAR) {
-            if constexpr (VEC) {
-                if constexpr (sizeof(T) == 4) {
-                    *(float4 *)(out + pix) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-                    *(float4 *)(out + plane + pix) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-                    *(float4 *)(out + 2 * plane + pix) = make_float4(c2[0], c2[1], c2[2], c2[3]);
-                } else {
-                    *(uchar4 *)(out + pix) = make_uchar4(c0[0], c0[1], c0[2], c0[3]);
-                    *(uchar4 *)(out + plane + pix) = make_uchar4(c1[0], c1[1], c1[2], c1[3]);
-                    *(uchar4 *)(out + 2 * plane + pix) = make_uchar4(c2[0], c2[1], c2[2], c2[3]);
-                }
-            } else {
-                for (int c = 0; c < ncol; c++) {
-                    out[pix + c] = c0[c];
-                    out[plane + pix + c] = c1[c];
-                    out[2 * plane + pix + c] = c2[c];
-                }
-            }
-        } else {
-            T *o = out + 3 * pix;
-            if constexpr (VEC) {
-                if constexpr (sizeof(T) == 4) {
-                    ((float4 *)o)[0] = make_float4(c0[0], c1[0], c2[0], c0[1]);
-                    ((float4 *)o)[1] = make_float4(c1[1], c2[1], c0[2], c1[2]);
-                    ((float4 *)o)[2] = make_float4(c2[2], c0[3], c1[3], c2[3]);
-                } else {
-                    ((uchar4 *)o)[0] = make_uchar4(c0[0], c1[0], c2[0], c0[1]);
-                    ((uchar4 *)o)[1] = make_uchar4(c1[1], c2[1], c0[2], c1[2]);
-                    ((uchar4 *)o)[2] = make_uchar4(c2[2], c0[3], c1[3], c2[3]);
-                }
-            } else {
-                for (int c = 0; c < ncol; c++) {
-                    o[3 * c] = c0[c];
-                    o[3 * c + 1] = c1[c];
-                    o[3 * c + 2] = c2[c];
-                }
-            }
+// ----------------------------------------------------------------------------------------------
+// Fallback kernel: taps gathered byte-wise from global memory (any size, any alignment).
+template <int MODE, int OUT, bool VEC>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_fused_gather_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = (id.tx * d.tx + lx) * PXW;
+    const int i0 = (id.ty * d.ty + ly) * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    GlobalSrc s;
+    s.y = t.y[id.frame];
+    s.uv = t.uv[id.frame];
+    s.py = d.pitch_y;
+    s.puv = d.pitch_uv;
+    s.w = d.src_w;
+    s.h = d.src_h;
+    convert_thread_tile<MODE, OUT, VEC>(s, d, (T *)t.out[id.frame], i0, j0);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Source footprint of a run of outputs [o0, o1] along one axis: first and last source sample any
+// of them taps, from the SAME coordinate functions the samplers use (they are monotonic in o).
+template <int MODE>
+__device__ __forceinline__ void axis_span(int o0, int o1, float ratio, int limit, int taps, int &lo, int &hi) {
+    if constexpr (MODE == M_NONE) {
+        lo = o0;
+        hi = o1;
+    } else if constexpr (MODE == M_NEAREST) {
+        lo = (int)(ratio * (float)o0);
+        hi = (int)(ratio * (float)o1);
+    } else if constexpr (MODE == M_AREA_DOWN) {
+        lo = (int)(ratio * (float)o0);
+        hi = (int)(ratio * (float)o1) + taps - 1;
+    } else if constexpr (MODE == M_BILINEAR) {
+        float w;
+        bilinear_axis(o0, ratio, limit, lo, w);
+        bilinear_axis(o1, ratio, limit, hi, w);
+        hi += 1;
+    } else if constexpr (MODE == M_AREA_UP) {
+        float w;
+        areaup_axis(o0, ratio, lo, w);
+        areaup_axis(o1, ratio, hi, w);
+        hi += 1;
+    } else { // M_BICUBIC
+        double w;
+        bicubic_axis(o0, ratio, limit, lo, w);
+        bicubic_axis(o1, ratio, limit, hi, w);
+        lo -= 1;
+        hi += 2;
+    }
+}
+
+// Footprint of one workgroup tile in both planes (luma columns/rows; chroma PAIR columns/rows).
+struct Footprint {
+    int j_first, i_first, j_last, i_last;
+    int xlo, xhi, ylo, yhi, cxlo, cxhi, cylo, cyhi;
+};
+template <int MODE>
+__device__ __forceinline__ Footprint tile_footprint(const LaunchDesc &d, const TileId &id) {
+    Footprint f;
+    f.j_first = id.tx * d.tx * PXW;
+    f.i_first = id.ty * d.ty * PXH;
+    f.j_last = min(f.j_first + d.tx * PXW, d.dst_w) - 1;
+    f.i_last = min(f.i_first + d.ty * PXH, d.dst_h) - 1;
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+    axis_span<MODE>(f.j_first, f.j_last, d.xr, d.src_w, d.rx, f.xlo, f.xhi);
+    axis_span<MODE>(f.i_first, f.i_last, d.yr, d.src_h, d.ry, f.ylo, f.yhi);
+    f.xlo = max(f.xlo, 0);
+    f.ylo = max(f.ylo, 0);
+    f.xhi = min(f.xhi, d.src_w - 1);
+    f.yhi = min(f.yhi, d.src_h - 1);
+    // chroma: the same formulas on the chroma grid (dst_w, dst_h are even)
+    axis_span<MODE>(f.j_first >> 1, f.j_last >> 1, d.xr, d.src_w, d.rx, f.cxlo, f.cxhi);
+    axis_span<MODE>(f.i_first >> 1, f.i_last >> 1, d.yr, d.src_h, d.ry, f.cylo, f.cyhi);
+    f.cxlo = max(f.cxlo, 0);
+    f.cylo = max(f.cylo, 0);
+    f.cxhi = min(f.cxhi, cw - 1);
+    f.cyhi = min(f.cyhi, chh - 1);
+    return f;
+}
+
+// Describe / stage rows [row_lo, row_lo + nrows) x byte columns [col_lo, col_lo + span) of one
+// plane into LDS with 16-byte aligned global loads.  A 16-byte aligned chunk that overlaps at
+// least one valid byte lies in the same page as that byte, so the over-read at the ends of a row
+// never faults.  2^slot_shift lanes serve one row (lanes >= cpr idle): no integer division.
+__device__ __forceinline__ LdsPlane describe_plane(uint8_t *lds, const uint8_t *plane, int pitch, int row_lo, int col_lo, int cpr,
+                                                   const uint8_t *&a0) {
+    a0 = plane + (size_t)row_lo * (size_t)pitch + (size_t)col_lo;
+    LdsPlane lp;
+    lp.base = lds;
+    lp.x0 = col_lo;
+    lp.y0 = row_lo;
+    lp.lp = 16 * cpr;
+    lp.m0 = (int)((uintptr_t)a0 & 15);
+    lp.pm = pitch & 15;
+    return lp;
+}
+__device__ __forceinline__ void stage_plane(uint8_t *lds, const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span, int cpr,
+                                            int slot_shift, int nthreads) {
+    const int c = threadIdx.x & ((1 << slot_shift) - 1);
+    const int rstep = nthreads >> slot_shift;
+    if (c >= cpr) return;
+    for (int r = threadIdx.x >> slot_shift; r < nrows; r += rstep) {
+        const int mis = (lp.m0 + r * lp.pm) & 15;
+        if (16 * c < mis + span) {
+            const uint4 v = *(const uint4 *)(a0 + (size_t)r * (size_t)pitch - mis + 16 * c);
+            *(uint4 *)(lds + r * lp.lp + 16 * c) = v;
         }
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+
 // ----------------------------------------------------------------------------------------------
+// Generic staged kernel (NEAREST, BICUBIC, AREA-down): footprint in LDS, generic samplers.
 template <int MODE, int OUT>
-static hipError_t launch_mo(bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream) {
-    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block(TX * TY);
+__global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const Footprint f = tile_footprint<MODE>(d, id);
+
+    LdsSrc s;
+    s.w = d.src_w;
+    s.h = d.src_h;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    const uint8_t *ay, *auv;
+    s.py_ = describe_plane(lds_raw, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
+    s.puv_ = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
+    stage_plane(lds_raw, ay, s.py_, d.pitch_y, min(f.yhi - f.ylo + 1, d.lds_rows_y), min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_cpr_y,
+                d.lds_slot_y, nthreads);
+    stage_plane(lds_uv, auv, s.puv_, d.pitch_uv, min(f.cyhi - f.cylo + 1, d.lds_rows_uv), min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv),
+                d.lds_cpr_uv, d.lds_slot_uv, nthreads);
+    __syncthreads();
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    convert_thread_tile<MODE, OUT, true>(s, d, (T *)t.out[id.frame], i0, j0);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fast kernel for the 2x2-tap family (BILINEAR and the AREA up-scale variant).
+//   * per-workgroup coordinate tables in LDS: every output column / row of the tile gets its
+//     source offset and weight computed ONCE (one lane each) instead of once per thread;
+//   * one LDS address per tap row, the horizontal neighbours at immediate offsets;
+//   * blend and colour arithmetic on float pairs (packed VALU).
+// Right-edge rule of the reference (x + 1 >= width -> B = A, src/Resize.cu:7-8): the column just
+// past the plane is written into LDS as a copy of the last one, so B is always "the next byte".
+struct XEntry { int off; float w; };                  // LDS byte offset from the row base, weight
+struct YEntry { int top, bot; float w; int pad; };    // LDS row bases of y and y2, weight
+
+template <bool AREAUP>
+__device__ __forceinline__ void axis2(int idx, float ratio, int limit, int &p, float &w) {
+    if constexpr (AREAUP) areaup_axis(idx, ratio, p, w);
+    else bilinear_axis(idx, ratio, limit, p, w);
+}
+
+template <bool AREAUP, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    constexpr int MODE = AREAUP ? M_AREA_UP : M_BILINEAR;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const Footprint f = tile_footprint<MODE>(d, id);
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    XEntry *xtab = (XEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    XEntry *cxtab = xtab + tw;
+    YEntry *ytab = (YEntry *)(cxtab + (tw >> 1));
+    YEntry *cytab = ytab + th;
+
+    const uint8_t *ay, *auv;
+    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
+    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    if (!(d.ablate & 2)) {
+        stage_plane(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_cpr_y, d.lds_slot_y, nthreads);
+        stage_plane(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_cpr_uv, d.lds_slot_uv, nthreads);
+    }
+
+    // coordinate tables (one entry per lane)
+    const int ntab = tw + (tw >> 1) + th + (th >> 1);
+    for (int e = threadIdx.x; e < ntab; e += nthreads) {
+        int p;
+        float w;
+        if (e < tw) {
+            axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
+            xtab[e] = XEntry{ p - f.xlo, w };
+        } else if (e < tw + (tw >> 1)) {
+            const int k = e - tw;
+            axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
+            cxtab[k] = XEntry{ 2 * (p - f.cxlo), w };
+        } else if (e < tw + (tw >> 1) + th) {
+            const int k = e - tw - (tw >> 1);
+            axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
+            const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo; // y + 1 >= height -> same row
+            ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15), w, 0 };
+        } else {
+            const int k = e - tw - (tw >> 1) - th;
+            axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
+            const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
+            cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15), w, 0 };
+        }
+    }
+    __syncthreads();
+    // replicate the last column / chroma pair one step past the plane (tiles on the right edge only)
+    const bool edge_y = (f.xhi == d.src_w - 1), edge_uv = (f.cxhi == cw - 1);
+    if (edge_y || edge_uv) {
+        if (edge_y)
+            for (int r = threadIdx.x; r < ny; r += nthreads) {
+                uint8_t *q = lds_y + r * py.lp + ((py.m0 + r * py.pm) & 15) + (d.src_w - f.xlo);
+                q[0] = q[-1];
+            }
+        if (edge_uv)
+            for (int r = threadIdx.x; r < nuv; r += nthreads) {
+                uint8_t *q = lds_uv + r * puv.lp + ((puv.m0 + r * puv.pm) & 15) + 2 * (cw - f.cxlo);
+                q[0] = q[-2];
+                q[1] = q[-1];
+            }
+        __syncthreads();
+    }
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+
+    // this thread's table entries: 4 luma columns, 2 luma rows, 2 chroma columns, 1 chroma row
+    XEntry xe[PXW], cxe[2];
+    YEntry ye[PXH], cye;
+    {
+        const uint4 a = *(const uint4 *)(xtab + lx * PXW), b = *(const uint4 *)(xtab + lx * PXW + 2);
+        xe[0] = XEntry{ (int)a.x, __uint_as_float(a.y) };
+        xe[1] = XEntry{ (int)a.z, __uint_as_float(a.w) };
+        xe[2] = XEntry{ (int)b.x, __uint_as_float(b.y) };
+        xe[3] = XEntry{ (int)b.z, __uint_as_float(b.w) };
+        const uint4 c = *(const uint4 *)(cxtab + lx * 2);
+        cxe[0] = XEntry{ (int)c.x, __uint_as_float(c.y) };
+        cxe[1] = XEntry{ (int)c.z, __uint_as_float(c.w) };
+        const uint4 y0 = *(const uint4 *)(ytab + ly * PXH), y1 = *(const uint4 *)(ytab + ly * PXH + 1);
+        ye[0] = YEntry{ (int)y0.x, (int)y0.y, __uint_as_float(y0.z), 0 };
+        ye[1] = YEntry{ (int)y1.x, (int)y1.y, __uint_as_float(y1.z), 0 };
+        const uint4 cy = *(const uint4 *)(cytab + ly);
+        cye = YEntry{ (int)cy.x, (int)cy.y, __uint_as_float(cy.z), 0 };
+    }
+
+    // chroma: (U, V) of one block blended as a float pair
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    if (d.ablate & 4) { // profiling: staging + stores only
+        for (int c = 0; c < 2; c++) Uf[c] = Vf[c] = (float)lds_uv[cye.top + cxe[c].off];
+        for (int r = 0; r < PXH; r++)
+            for (int c = 0; c < PXW; c++) Yf[r][c] = (float)lds_y[ye[r].top + xe[c].off];
+        st4((float *)t.out[id.frame] + (size_t)i0 * d.dst_w + j0, Yf[0][0], Yf[0][1], Uf[0], Vf[0], 0);
+        const size_t plane = (size_t)d.dst_w * d.dst_h;
+        float *o = (float *)t.out[id.frame];
+        for (int r = 0; r < PXH; r++)
+            for (int p = 0; p < 3; p++) st4(o + p * plane + (size_t)(i0 + r) * d.dst_w + j0, Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3], d.nt_stores);
+        return;
+    }
+    {
+        const f2 wy = { cye.w, cye.w }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            // one address per row, taps at immediate offsets 0..3 (U0 V0 U1 V1); unaligned wide LDS
+            // reads are serialised by the hardware, so the taps are byte reads
+            const uint8_t *top = lds_uv + cye.top + cxe[c].off, *bot = lds_uv + cye.bot + cxe[c].off;
+            const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
+            const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
+            const f2 wx = { cxe[c].w, cxe[c].w }, omx = (f2){ 1.0f, 1.0f } - wx;
+            f2 sum = (A * omx) * omy + (B * wx) * omy;
+            sum = sum + (C * wy) * omx;
+            sum = sum + D * (wx * wy);
+            Uf[c] = __builtin_truncf(sum.x);
+            Vf[c] = __builtin_truncf(sum.y);
+        }
+    }
+    // luma: horizontally adjacent pixel pairs
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const f2 wy = { ye[r].w, ye[r].w }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const uint8_t *t0 = lds_y + ye[r].top + xe[2 * p].off, *t1 = lds_y + ye[r].top + xe[2 * p + 1].off;
+            const uint8_t *b0 = lds_y + ye[r].bot + xe[2 * p].off, *b1 = lds_y + ye[r].bot + xe[2 * p + 1].off;
+            const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
+            const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
+            const f2 wx = { xe[2 * p].w, xe[2 * p + 1].w }, omx = (f2){ 1.0f, 1.0f } - wx;
+            f2 sum = (A * omx) * omy + (B * wx) * omy;
+            sum = sum + (C * wy) * omx;
+            sum = sum + D * (wx * wy);
+            Yf[r][2 * p] = __builtin_truncf(sum.x);
+            Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
+        }
+    }
+    if (d.ablate & 1) { // profiling: keep the arithmetic alive without the HBM writes
+        float acc = Uf[0] + Vf[0] + Uf[1] + Vf[1];
+        for (int r = 0; r < PXH; r++)
+            for (int c = 0; c < PXW; c++) acc += Yf[r][c];
+        if (acc == -1.0f) ((float *)t.out[id.frame])[0] = acc;
+        return;
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Host side of the launch: tile geometry, LDS budget, kernel selection.
+static int span_bound(Mode m, int n_out, float ratio, int taps) {
+    // max over tile positions of (last tap - first tap + 1) for n_out consecutive outputs, +1 spare
+    int ext = 0;
+    switch (m) {
+    case M_BILINEAR: case M_AREA_UP: ext = 1; break;
+    case M_BICUBIC: ext = 3; break;
+    case M_AREA_DOWN: ext = taps - 1; break;
+    default: ext = 0; break;
+    }
+    return (int)((double)ratio * (double)(n_out - 1)) + ext + 3;
+}
+static int slot_shift_for(int cpr) {
+    int s = 0;
+    while ((1 << s) < cpr) s++;
+    return s;
+}
+
+template <int MODE, int OUT>
+static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream) {
+    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
+    if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
+        if (staged) {
+            hipLaunchKernelGGL((vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes, stream, d, t);
+            return hipGetLastError();
+        }
+    } else if constexpr (MODE != M_NONE) {
+        if (staged) {
+            hipLaunchKernelGGL((vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes, stream, d, t);
+            return hipGetLastError();
+        }
+    }
     if (vec)
-        hipLaunchKernelGGL((vpp_fused_kernel<MODE, OUT, true>), grid, block, 0, stream, d, t);
+        hipLaunchKernelGGL((vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0, stream, d, t);
     else
-        hipLaunchKernelGGL((vpp_fused_kernel<MODE, OUT, false>), grid, block, 0, stream, d, t);
+        hipLaunchKernelGGL((vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0, stream, d, t);
     return hipGetLastError();
 }
 
 template <int MODE>
-static hipError_t launch_m(OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream) {
+static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds, hipStream_t stream) {
     switch (out) {
-    case O_U8_PLANAR: return launch_mo<MODE, O_U8_PLANAR>(vec, d, t, stream);
-    case O_U8_MERGED: return launch_mo<MODE, O_U8_MERGED>(vec, d, t, stream);
-    case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, d, t, stream);
-    case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, d, t, stream);
+    case O_U8_PLANAR: return launch_mo<MODE, O_U8_PLANAR>(vec, staged, d, t, lds, stream);
+    case O_U8_MERGED: return launch_mo<MODE, O_U8_MERGED>(vec, staged, d, t, lds, stream);
+    case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, staged, d, t, lds, stream);
+    case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, staged, d, t, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream) {
     LaunchDesc d = din;
-    d.tiles_x = (d.dst_w + TILE_W - 1) / TILE_W;
-    d.tiles_y = (d.dst_h + TILE_H - 1) / TILE_H;
+    // Candidate workgroup shapes, largest first; the staged kernels take the first whose source
+    // footprint fits the LDS budget (several workgroups per CU must stay resident to overlap one
+    // group's loads with another's arithmetic).
+    int shapes[4][2] = { { 32, 8 }, { 32, 4 }, { 16, 4 }, { 0, 0 } };
+    if (d.shape_tx > 0 && d.shape_ty > 0 && (d.shape_tx & (d.shape_tx - 1)) == 0 && d.shape_tx * d.shape_ty <= MAX_THREADS &&
+        d.shape_tx * d.shape_ty >= 64) {
+        shapes[0][0] = d.shape_tx;
+        shapes[0][1] = d.shape_ty;
+    }
+    constexpr size_t kLdsBudget = 40 * 1024;
+    bool staged = false;
+    size_t lds_bytes = 0;
+    d.tx = shapes[0][0];
+    d.ty = shapes[0][1];
+    if (mode != M_NONE && vec && !d.force_gather) {
+        for (auto &sh : shapes) {
+            if (sh[0] == 0) break;
+            const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
+            const int rows_y = span_bound(mode, sh[1] * PXH, d.yr, d.ry);
+            const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
+            const int rows_uv = span_bound(mode, sh[1] * PXH / 2, d.yr, d.ry);
+            const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
+            const int nthreads = sh[0] * sh[1];
+            if (cpr_y > nthreads || cpr_uv > nthreads) continue;
+            size_t need = (size_t)16 * ((size_t)rows_y * cpr_y + (size_t)rows_uv * cpr_uv);
+            if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
+                need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
+            if (need <= kLdsBudget) {
+                staged = true;
+                lds_bytes = need;
+                d.tx = sh[0];
+                d.ty = sh[1];
+                d.lds_span_y = span_y;
+                d.lds_rows_y = rows_y;
+                d.lds_cpr_y = cpr_y;
+                d.lds_slot_y = slot_shift_for(cpr_y);
+                d.lds_span_uv = span_uv;
+                d.lds_rows_uv = rows_uv;
+                d.lds_cpr_uv = cpr_uv;
+                d.lds_slot_uv = slot_shift_for(cpr_uv);
+                break;
+            }
+        }
+    }
+    d.tx_shift = slot_shift_for(d.tx);
+    const int tile_w = d.tx * PXW, tile_h = d.ty * PXH;
+    d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
+    d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
     d.blocks_per_xcd = (int)((total + NUM_XCD - 1) / NUM_XCD);
     switch (mode) {
-    case M_NONE: return launch_m<M_NONE>(out, vec, d, t, stream);
-    case M_NEAREST: return launch_m<M_NEAREST>(out, vec, d, t, stream);
-    case M_BILINEAR: return launch_m<M_BILINEAR>(out, vec, d, t, stream);
-    case M_BICUBIC: return launch_m<M_BICUBIC>(out, vec, d, t, stream);
-    case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, vec, d, t, stream);
-    case M_AREA_UP: return launch_m<M_AREA_UP>(out, vec, d, t, stream);
+    case M_NONE: return launch_m<M_NONE>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_NEAREST: return launch_m<M_NEAREST>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_BILINEAR: return launch_m<M_BILINEAR>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_BICUBIC: return launch_m<M_BICUBIC>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_AREA_UP: return launch_m<M_AREA_UP>(out, vec, staged, d, t, lds_bytes, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -155,6 +155,24 @@ class VideoProcessor:
         N.check(self._lib.tsvpp_convert_batch(self._ctx, n, frames, ctypes.byref(p), outs, stream))
         return out
 
+    def make_batch(self, ys, uvs, params, out=None, width=None, height=None):
+        """Pre-builds the descriptor arrays of a batch (the per-frame structs are built once, not per
+        call): returns a handle for run_batch().  Keeps the tensors alive."""
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        n = len(ys)
+        frames = (N.NV12 * n)(*[self._frame(ys[i], uvs[i], width, height) for i in range(n)])
+        if out is None:
+            out = self._alloc(p, frames[0].width, frames[0].height, n)
+        outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        return {"n": n, "frames": frames, "outs": outs, "params": p, "out": out, "keep": (ys, uvs)}
+
+    def run_batch(self, batch, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.tsvpp_convert_batch(self._ctx, batch["n"], batch["frames"], ctypes.byref(batch["params"]),
+                                              batch["outs"], stream))
+        return batch["out"]
+
     def _on_consumer_stream(self, name):
         raw = self.consumer_stream(name)
         ext = torch.cuda.ExternalStream(raw, device=self.device)

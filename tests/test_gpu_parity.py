@@ -182,6 +182,30 @@ def test_errors(vpp):
         vpp.Convert(y, uv, ts.FrameParameters(crop_coords=(600, 0, 700, 100)))  # crop box outside the frame
 
 
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+def test_gather_fallback_kernel_matches_too(oracle, rt, monkeypatch):
+    """The global-gather kernel (used for huge footprints / dst_w % 4 != 0) stays covered by forcing it."""
+    import tensor_stream as ts
+    monkeypatch.setenv("TSVPP_FORCE_GATHER", "1")
+    v = ts.VideoProcessor(device=0)
+    monkeypatch.delenv("TSVPP_FORCE_GATHER")
+    y, uv = synth_nv12(1080, 608, seed=31 + rt)
+    check(v, oracle, y, uv, dst=(480, 360), resize_type=rt, fourcc=BGR24, planes=PLANAR, normalization=True)
+    check(v, oracle, y, uv, crop=(121, 65, 601, 401), dst=(300, 200), resize_type=rt, planes=MERGED)
+    v.Close()
+
+
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
+@pytest.mark.parametrize("src,dst", [((3840, 2160), (224, 224)),     # ratio 17 x 9.6: footprint too big for LDS -> gather
+                                     ((3840, 2160), (640, 360)),     # ratio 6: smaller workgroup shape
+                                     ((1920, 1080), (3840, 2160)),   # 2x up-scale
+                                     ((1280, 720), (1920, 1080)),    # 1.5x up-scale
+                                     ((1922, 1082), (1284, 724))])   # unaligned pitch: per-row LDS shift
+def test_staging_shapes(vpp, oracle, rt, src, dst):
+    y, uv = synth_nv12(src[0], src[1], seed=rt * 7 + dst[0])
+    check(vpp, oracle, y, uv, dst=dst, resize_type=rt, fourcc=BGR24, planes=PLANAR, normalization=False)
+
+
 def test_consumer_pool_semantics(vpp):
     """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
     (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
