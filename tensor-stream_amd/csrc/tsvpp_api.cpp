@@ -87,7 +87,7 @@ struct tsvpp_ctx {
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
     int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
-    int nt_stores = 0, no_xcd_remap = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_NO_XCD, TSVPP_SHAPE=tx,ty
+    int nt_stores = 0, no_xcd_remap = 1, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_XCD_REMAP, TSVPP_SHAPE=tx,ty
     int ablate = 0;
     std::mutex area_mu;
 };
@@ -210,7 +210,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
     if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = (e[0] == '1');
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_NO_XCD")) ctx->no_xcd_remap = (e[0] == '1');
+    if (const char *e = std::getenv("TSVPP_XCD_REMAP")) ctx->no_xcd_remap = (e[0] == '1') ? 0 : 1;
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
     for (int i = 0; i < max_consumers; i++) {
         hipStream_t s = nullptr;
@@ -347,6 +347,10 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // exactly as it does in the reference)
     const size_t y_off = (size_t)pl.off_y * (size_t)pitch_y + (size_t)pl.off_x;
     const size_t uv_off = (size_t)(pl.off_y / 2) * (size_t)pitch_uv + (size_t)pl.off_x;
+    bool aligned4 = (pitch_y % 4 == 0) && (pitch_uv % 4 == 0);
+    for (int f = 0; f < n && aligned4; f++)
+        aligned4 = (((uintptr_t)(in[f].y + y_off)) % 4 == 0) && (((uintptr_t)(in[f].uv + uv_off)) % 4 == 0);
+    d.in_aligned4 = aligned4 ? 1 : 0;
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
         FrameTable t;

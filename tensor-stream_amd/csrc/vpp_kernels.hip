@@ -426,9 +426,10 @@ __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const
 }
 
 // ----------------------------------------------------------------------------------------------
-// Work decomposition shared by all kernels.  XCD-aware: consecutive workgroup ids land on
-// different XCDs (id % 8), so every XCD gets a contiguous run of (frame, tile) work and
-// neighbouring tiles share their source halo rows in ONE L2 instead of fetching them into two.
+// Work decomposition shared by all kernels: workgroup id -> (frame, tile) in raster order, so that
+// at any moment all 8 XCDs write into the same few hundred KiB of one frame (measured +2..5 % over
+// the XCD-contiguous mapping, which trades that HBM write locality for L2 reuse of the few halo
+// rows; the remap stays available behind TSVPP_XCD_REMAP=1 for A/B runs).
 struct TileId {
     int frame, tx, ty;
     bool valid;
@@ -782,6 +783,36 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 }
 
 // ----------------------------------------------------------------------------------------------
+// Colour-only kernel (no resize; crop is already folded into the pointers): thread = 2 rows x 4
+// pixels, 4-byte coalesced luma loads, one 4-byte chroma load (2 pairs) shared by the two rows.
+// Every store instruction of a wave covers one contiguous run (lane stride 16 B): two 16-byte
+// pieces per lane would leave each instruction writing half lines.  Needs 4-byte aligned rows.
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_color_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = (id.tx * d.tx + lx) * PXW;
+    const int i0 = (id.ty * d.ty + ly) * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const uint8_t *py = t.y[id.frame] + (size_t)i0 * (size_t)d.pitch_y + (size_t)j0;
+    const uint32_t yw[2] = { *(const uint32_t *)py, *(const uint32_t *)(py + d.pitch_y) };
+    const uint32_t c = *(const uint32_t *)(t.uv[id.frame] + (size_t)(i0 >> 1) * (size_t)d.pitch_uv + (size_t)j0);
+    const float Uf[2] = { (float)(c & 255), (float)((c >> 16) & 255) };
+    const float Vf[2] = { (float)((c >> 8) & 255), (float)(c >> 24) };
+    float Yf[PXH][PXW];
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        Yf[r][0] = (float)(yw[r] & 255);
+        Yf[r][1] = (float)((yw[r] >> 8) & 255);
+        Yf[r][2] = (float)((yw[r] >> 16) & 255);
+        Yf[r][3] = (float)(yw[r] >> 24);
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Host side of the launch: tile geometry, LDS budget, kernel selection.
 static int span_bound(Mode m, int n_out, float ratio, int taps) {
     // max over tile positions of (last tap - first tap + 1) for n_out consecutive outputs, +1 spare
@@ -811,6 +842,11 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     } else if constexpr (MODE != M_NONE) {
         if (staged) {
             hipLaunchKernelGGL((vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes, stream, d, t);
+            return hipGetLastError();
+        }
+    } else {
+        if (staged) { // colour-only fast path ("staged" = eligible)
+            hipLaunchKernelGGL((vpp_color_kernel<OUT>), grid, block, 0, stream, d, t);
             return hipGetLastError();
         }
     }
@@ -878,6 +914,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             }
         }
     }
+    if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     d.tx_shift = slot_shift_for(d.tx);
     const int tile_w = d.tx * PXW, tile_h = d.ty * PXH;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;

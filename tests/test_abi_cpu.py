@@ -144,6 +144,21 @@ def test_python_frame_parameters_defaults(native):
     assert ts.output_shape(ts.FrameParameters().parameters, 320, 240) == (240, 320, 3)
 
 
+def test_cpp_host_library_links_against_the_abi(native):
+    """libtsvpp_host.so (class VideoProcessor) is built and resolves every tsvpp_* it uses from libtsvpp.so."""
+    import subprocess
+    host = os.path.join(os.path.dirname(native.LIB_PATH), "libtsvpp_host.so")
+    if not os.path.exists(host):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.run(["nm", "-D", "--undefined-only", host], capture_output=True, text=True).stdout
+    used = set(re.findall(r"\b(tsvpp_[a-z0-9_]+)", out))
+    assert {"tsvpp_create", "tsvpp_convert", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_destroy"} <= used
+    assert used <= set(native.SYMBOLS)
+    defined = subprocess.run(["nm", "-D", "--defined-only", host], capture_output=True, text=True).stdout
+    assert "VideoProcessor7Convert" in defined and "VideoProcessor4Init" in defined and "channelsByFourCC" in defined
+
+
 def test_no_product_code_touches_the_oracle():
     """The product path must never import, link or call anything under oracle/."""
     pkg = os.path.join(ROOT, "tensor-stream_amd")
