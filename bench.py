@@ -197,9 +197,18 @@ def main():
                        "parity": parity},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "vpp_fused_kernel", "bytes_per_frame": bytes_per_frame,
+                         "kernel": "tsvpp::vpp_*_kernel (one fused launch)", "bytes_per_frame": bytes_per_frame,
                          "avg_launch_ms": round(kernel_ms, 5), "host_issue_ms_per_step": round(host_issue * 1e3 / args.steps, 4)},
         }
+        # HBM traffic per launch from the committed PMC passes (tools/profile.sh -> tools/traffic_json.py); the counters
+        # need their own rocprofv3 runs, so this is the last profiled value for this workload, not a live one
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json"))).get(args.workload if not args.resize else "")
+            if tr and tr["frames_per_launch"] == frames_per_launch:
+                res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = f"profiles/traffic_latest.json ({tr['round']}): 2*FETCH_SIZE+WRITE_SIZE, KiB"
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(res), flush=True)

@@ -5,4 +5,5 @@ head -4 $S/kt/kt_kernel_stats.csv > $D/${R}_${T}_kernel_stats.csv
 { echo "# rocprofv3 PMC means per dispatch of the tsvpp kernel (separate passes), workload: $T";
   python tools/pmc_summary.py $S/pmc_sq/sq_counter_collection.csv $S/pmc_lds/lds_counter_collection.csv $S/pmc_fetch/fetch_counter_collection.csv $S/pmc_write/write_counter_collection.csv; } > $D/${R}_${T}_pmc.txt
 grep -h '"metric"' $S/kt.log | tail -1 > $D/${R}_${T}_bench_under_rocprof.json
+python tools/traffic_json.py $R $T $S
 ls -la $D
