@@ -87,8 +87,9 @@ struct tsvpp_ctx {
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
     int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
-    int nt_stores = 0, no_xcd_remap = 1, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_XCD_REMAP, TSVPP_SHAPE=tx,ty
+    int nt_stores = 0, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
+    int persist = 0, num_cus = 256; // TSVPP_PERSIST
     std::mutex area_mu;
 };
 
@@ -210,7 +211,12 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
     if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = (e[0] == '1');
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_XCD_REMAP")) ctx->no_xcd_remap = (e[0] == '1') ? 0 : 1;
+    if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
+    }
+    if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
     for (int i = 0; i < max_consumers; i++) {
         hipStream_t s = nullptr;
@@ -325,10 +331,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.k = ctx->coeffs;
     d.force_gather = ctx->force_gather;
     d.nt_stores = ctx->nt_stores;
-    d.no_xcd_remap = ctx->no_xcd_remap;
+    d.tile_order = ctx->tile_order;
     d.shape_tx = ctx->shape_tx;
     d.shape_ty = ctx->shape_ty;
     d.ablate = ctx->ablate;
+    d.persist = ctx->persist;
+    d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;
         sts = get_area_table(ctx, pl.xr, tx);

@@ -45,8 +45,10 @@ struct LaunchDesc {
     int force_gather; // debugging / A-B: 1 = always use the global-gather kernel
     // tuning knobs (ctx options / TSVPP_* environment, see tsvpp_api.cpp)
     int nt_stores;    // 1 = non-temporal output stores
-    int no_xcd_remap; // 1 = workgroup id -> tile in plain raster order
+    int tile_order;   // 0 = tile row per XCD (default), 1 = raster, 2 = XCD-contiguous runs
     int shape_tx, shape_ty; // != 0: force the workgroup shape
+    int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
+    int num_cus;            // compute units of the device (persistent grid sizing)
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
 };
 

@@ -426,20 +426,32 @@ __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const
 }
 
 // ----------------------------------------------------------------------------------------------
-// Work decomposition shared by all kernels: workgroup id -> (frame, tile) in raster order, so that
-// at any moment all 8 XCDs write into the same few hundred KiB of one frame (measured +2..5 % over
-// the XCD-contiguous mapping, which trades that HBM write locality for L2 reuse of the few halo
-// rows; the remap stays available behind TSVPP_XCD_REMAP=1 for A/B runs).
+// Work decomposition shared by all kernels.
 struct TileId {
     int frame, tx, ty;
     bool valid;
 };
+// tile_order 0 (default): workgroup id -> tile such that (a) the workgroups resident at any moment
+// cover a contiguous run of tile rows of one or two frames (HBM write locality: measured +2..5 %
+// over giving each XCD its own frames) and (b) a whole tile ROW lands on one XCD (id % 8), so the
+// 128-byte lines that horizontally adjacent tiles share are fetched into one L2 once.
+// tile_order 1: plain raster.  tile_order 2: XCD-contiguous runs of (frame, tile).
 __device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
     TileId t;
-    const int total = d.tiles_x * d.tiles_y * d.n_frames;
-    const int logical = d.no_xcd_remap ? (int)blockIdx.x : (int)((blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD);
-    t.valid = logical < total;
     const int tiles = d.tiles_x * d.tiles_y;
+    if (d.tile_order == 0) {
+        const int x = blockIdx.x % NUM_XCD, q = blockIdx.x / NUM_XCD;
+        const int group = q / d.tiles_x;
+        t.tx = q - group * d.tiles_x;
+        const int row = group * NUM_XCD + x; // global tile row = frame * tiles_y + ty
+        t.frame = row / d.tiles_y;
+        t.ty = row - t.frame * d.tiles_y;
+        t.valid = row < d.tiles_y * d.n_frames;
+        return t;
+    }
+    const int total = tiles * d.n_frames;
+    const int logical = d.tile_order == 1 ? (int)blockIdx.x : (int)((blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD);
+    t.valid = logical < total;
     t.frame = logical / tiles;
     const int rem = logical - t.frame * tiles;
     t.ty = rem / d.tiles_x;
@@ -570,17 +582,52 @@ __device__ __forceinline__ LdsPlane describe_plane(uint8_t *lds, const uint8_t *
     lp.pm = pitch & 15;
     return lp;
 }
-__device__ __forceinline__ void stage_plane(uint8_t *lds, const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span, int cpr,
-                                            int slot_shift, int nthreads) {
-    const int c = threadIdx.x & ((1 << slot_shift) - 1);
-    const int rstep = nthreads >> slot_shift;
-    if (c >= cpr) return;
-    for (int r = threadIdx.x >> slot_shift; r < nrows; r += rstep) {
-        const int mis = (lp.m0 + r * lp.pm) & 15;
-        if (16 * c < mis + span) {
-            const uint4 v = *(const uint4 *)(a0 + (size_t)r * (size_t)pitch - mis + 16 * c);
-            *(uint4 *)(lds + r * lp.lp + 16 * c) = v;
-        }
+// All loads of a round -- both planes -- are issued before the first LDS write (K rows per lane in
+// flight): with a plain load->write loop the compiler has to wait for each chunk before issuing
+// the next and the workgroup pays the HBM latency once per row group instead of once.  The loads
+// are branch-free (clamped addresses; only the LDS write is predicated).
+struct StageLane {
+    int ch, r0, rstep;
+};
+__device__ __forceinline__ StageLane stage_lane(int slot_shift, int nthreads) {
+    return StageLane{ (int)(threadIdx.x & ((1 << slot_shift) - 1)), (int)(threadIdx.x >> slot_shift), nthreads >> slot_shift };
+}
+template <int K>
+__device__ __forceinline__ void stage_issue(const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span, int cpr, const StageLane &ln,
+                                            int base, uint4 v[K], bool ok[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = base + k * ln.rstep + ln.r0;
+        const int rc = min(r, nrows - 1);
+        const int mis = (lp.m0 + rc * lp.pm) & 15;
+        const int chmax = (mis + span - 1) >> 4;
+        ok[k] = (ln.ch < cpr) && (r < nrows) && (ln.ch <= chmax);
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (base + k * ln.rstep < nrows) // uniform
+            v[k] = *(const uint4 *)(a0 + (size_t)rc * (size_t)pitch - mis + 16 * min(ln.ch, chmax));
+    }
+}
+template <int K>
+__device__ __forceinline__ void stage_commit(uint8_t *lds, const LdsPlane &lp, const StageLane &ln, int base, const uint4 v[K], const bool ok[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = base + k * ln.rstep + ln.r0;
+        if (ok[k]) *(uint4 *)(lds + r * lp.lp + 16 * ln.ch) = v[k];
+    }
+}
+template <int KY, int KUV>
+__device__ __forceinline__ void stage_planes(const LaunchDesc &d, uint8_t *lds_y, const uint8_t *ay, const LdsPlane &py, int ny, int span_y,
+                                             uint8_t *lds_uv, const uint8_t *auv, const LdsPlane &puv, int nuv, int span_uv, int nthreads) {
+    const StageLane ly = stage_lane(d.lds_slot_y, nthreads), luv = stage_lane(d.lds_slot_uv, nthreads);
+    for (int it = 0;; it++) {
+        const int by = it * KY * ly.rstep, buv = it * KUV * luv.rstep;
+        if (by >= ny && buv >= nuv) break;
+        uint4 vy[KY], vuv[KUV];
+        bool oky[KY], okuv[KUV];
+        stage_issue<KY>(ay, py, d.pitch_y, ny, span_y, d.lds_cpr_y, ly, by, vy, oky);
+        stage_issue<KUV>(auv, puv, d.pitch_uv, nuv, span_uv, d.lds_cpr_uv, luv, buv, vuv, okuv);
+        stage_commit<KY>(lds_y, py, ly, by, vy, oky);
+        stage_commit<KUV>(lds_uv, puv, luv, buv, vuv, okuv);
     }
 }
 
@@ -603,10 +650,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const Lau
     const uint8_t *ay, *auv;
     s.py_ = describe_plane(lds_raw, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     s.puv_ = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    stage_plane(lds_raw, ay, s.py_, d.pitch_y, min(f.yhi - f.ylo + 1, d.lds_rows_y), min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_cpr_y,
-                d.lds_slot_y, nthreads);
-    stage_plane(lds_uv, auv, s.puv_, d.pitch_uv, min(f.cyhi - f.cylo + 1, d.lds_rows_uv), min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv),
-                d.lds_cpr_uv, d.lds_slot_uv, nthreads);
+    stage_planes<4, 2>(d, lds_raw, ay, s.py_, min(f.yhi - f.ylo + 1, d.lds_rows_y), min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, s.puv_,
+                       min(f.cyhi - f.cylo + 1, d.lds_rows_uv), min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
     __syncthreads();
 
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
@@ -632,6 +677,95 @@ __device__ __forceinline__ void axis2(int idx, float ratio, int limit, int &p, f
     else bilinear_axis(idx, ratio, limit, p, w);
 }
 
+// Blend + colour-convert + store one thread tile of the 2x2-tap family from the staged LDS planes
+// and the coordinate tables.
+template <int OUT>
+__device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const XEntry *xtab,
+                                                     const XEntry *cxtab, const YEntry *ytab, const YEntry *cytab, int lx, int ly,
+                                                     typename OutT<OUT>::type *out, int i0, int j0) {
+    // this thread's table entries: 4 luma columns, 2 luma rows, 2 chroma columns, 1 chroma row
+    XEntry xe[PXW], cxe[2];
+    YEntry ye[PXH], cye;
+    {
+        const uint4 a = *(const uint4 *)(xtab + lx * PXW), b = *(const uint4 *)(xtab + lx * PXW + 2);
+        xe[0] = XEntry{ (int)a.x, __uint_as_float(a.y) };
+        xe[1] = XEntry{ (int)a.z, __uint_as_float(a.w) };
+        xe[2] = XEntry{ (int)b.x, __uint_as_float(b.y) };
+        xe[3] = XEntry{ (int)b.z, __uint_as_float(b.w) };
+        const uint4 c = *(const uint4 *)(cxtab + lx * 2);
+        cxe[0] = XEntry{ (int)c.x, __uint_as_float(c.y) };
+        cxe[1] = XEntry{ (int)c.z, __uint_as_float(c.w) };
+        const uint4 y0 = *(const uint4 *)(ytab + ly * PXH), y1 = *(const uint4 *)(ytab + ly * PXH + 1);
+        ye[0] = YEntry{ (int)y0.x, (int)y0.y, __uint_as_float(y0.z), 0 };
+        ye[1] = YEntry{ (int)y1.x, (int)y1.y, __uint_as_float(y1.z), 0 };
+        const uint4 cy = *(const uint4 *)(cytab + ly);
+        cye = YEntry{ (int)cy.x, (int)cy.y, __uint_as_float(cy.z), 0 };
+    }
+
+    // chroma: (U, V) of one block blended as a float pair
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    if (d.ablate & 4) { // profiling: staging + stores only
+        for (int c = 0; c < 2; c++) Uf[c] = Vf[c] = (float)lds_uv[cye.top + cxe[c].off];
+        for (int r = 0; r < PXH; r++)
+            for (int c = 0; c < PXW; c++) Yf[r][c] = (float)lds_y[ye[r].top + xe[c].off];
+        if (d.ablate & 1) { // loads only
+            float acc = Uf[0] + Vf[1];
+            for (int r = 0; r < PXH; r++)
+                for (int c = 0; c < PXW; c++) acc += Yf[r][c];
+            if (acc == -1.0f) ((float *)out)[0] = acc;
+            return;
+        }
+        const size_t plane = (size_t)d.dst_w * d.dst_h;
+        float *o = (float *)out;
+        for (int r = 0; r < PXH; r++)
+            for (int p = 0; p < 3; p++) st4(o + p * plane + (size_t)(i0 + r) * d.dst_w + j0, Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3], d.nt_stores);
+        return;
+    }
+    {
+        const f2 wy = { cye.w, cye.w }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            // one address per row, taps at immediate offsets 0..3 (U0 V0 U1 V1); unaligned wide LDS
+            // reads are serialised by the hardware, so the taps are byte reads
+            const uint8_t *top = lds_uv + cye.top + cxe[c].off, *bot = lds_uv + cye.bot + cxe[c].off;
+            const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
+            const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
+            const f2 wx = { cxe[c].w, cxe[c].w }, omx = (f2){ 1.0f, 1.0f } - wx;
+            f2 sum = (A * omx) * omy + (B * wx) * omy;
+            sum = sum + (C * wy) * omx;
+            sum = sum + D * (wx * wy);
+            Uf[c] = __builtin_truncf(sum.x);
+            Vf[c] = __builtin_truncf(sum.y);
+        }
+    }
+    // luma: horizontally adjacent pixel pairs
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const f2 wy = { ye[r].w, ye[r].w }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const uint8_t *t0 = lds_y + ye[r].top + xe[2 * p].off, *t1 = lds_y + ye[r].top + xe[2 * p + 1].off;
+            const uint8_t *b0 = lds_y + ye[r].bot + xe[2 * p].off, *b1 = lds_y + ye[r].bot + xe[2 * p + 1].off;
+            const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
+            const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
+            const f2 wx = { xe[2 * p].w, xe[2 * p + 1].w }, omx = (f2){ 1.0f, 1.0f } - wx;
+            f2 sum = (A * omx) * omy + (B * wx) * omy;
+            sum = sum + (C * wy) * omx;
+            sum = sum + D * (wx * wy);
+            Yf[r][2 * p] = __builtin_truncf(sum.x);
+            Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
+        }
+    }
+    if (d.ablate & 1) { // profiling: keep the arithmetic alive without the HBM writes
+        float acc = Uf[0] + Vf[0] + Uf[1] + Vf[1];
+        for (int r = 0; r < PXH; r++)
+            for (int c = 0; c < PXW; c++) acc += Yf[r][c];
+        if (acc == -1.0f) ((float *)out)[0] = acc;
+        return;
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+}
+
 template <bool AREAUP, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
@@ -655,8 +789,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     if (!(d.ablate & 2)) {
-        stage_plane(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_cpr_y, d.lds_slot_y, nthreads);
-        stage_plane(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_cpr_uv, d.lds_slot_uv, nthreads);
+        stage_planes<2, 1>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
+                           min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
     }
 
     // coordinate tables (one entry per lane)
@@ -705,81 +839,130 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
 
-    // this thread's table entries: 4 luma columns, 2 luma rows, 2 chroma columns, 1 chroma row
-    XEntry xe[PXW], cxe[2];
-    YEntry ye[PXH], cye;
-    {
-        const uint4 a = *(const uint4 *)(xtab + lx * PXW), b = *(const uint4 *)(xtab + lx * PXW + 2);
-        xe[0] = XEntry{ (int)a.x, __uint_as_float(a.y) };
-        xe[1] = XEntry{ (int)a.z, __uint_as_float(a.w) };
-        xe[2] = XEntry{ (int)b.x, __uint_as_float(b.y) };
-        xe[3] = XEntry{ (int)b.z, __uint_as_float(b.w) };
-        const uint4 c = *(const uint4 *)(cxtab + lx * 2);
-        cxe[0] = XEntry{ (int)c.x, __uint_as_float(c.y) };
-        cxe[1] = XEntry{ (int)c.z, __uint_as_float(c.w) };
-        const uint4 y0 = *(const uint4 *)(ytab + ly * PXH), y1 = *(const uint4 *)(ytab + ly * PXH + 1);
-        ye[0] = YEntry{ (int)y0.x, (int)y0.y, __uint_as_float(y0.z), 0 };
-        ye[1] = YEntry{ (int)y1.x, (int)y1.y, __uint_as_float(y1.z), 0 };
-        const uint4 cy = *(const uint4 *)(cytab + ly);
-        cye = YEntry{ (int)cy.x, (int)cy.y, __uint_as_float(cy.z), 0 };
-    }
+    bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[id.frame], i0, j0);
+}
 
-    // chroma: (U, V) of one block blended as a float pair
-    float Uf[2], Vf[2], Yf[PXH][PXW];
-    if (d.ablate & 4) { // profiling: staging + stores only
-        for (int c = 0; c < 2; c++) Uf[c] = Vf[c] = (float)lds_uv[cye.top + cxe[c].off];
-        for (int r = 0; r < PXH; r++)
-            for (int c = 0; c < PXW; c++) Yf[r][c] = (float)lds_y[ye[r].top + xe[c].off];
-        st4((float *)t.out[id.frame] + (size_t)i0 * d.dst_w + j0, Yf[0][0], Yf[0][1], Uf[0], Vf[0], 0);
-        const size_t plane = (size_t)d.dst_w * d.dst_h;
-        float *o = (float *)t.out[id.frame];
-        for (int r = 0; r < PXH; r++)
-            for (int p = 0; p < 3; p++) st4(o + p * plane + (size_t)(i0 + r) * d.dst_w + j0, Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3], d.nt_stores);
-        return;
-    }
+// ----------------------------------------------------------------------------------------------
+// Persistent variant of the 2x2-tap kernel.  The one-tile-per-workgroup kernel above exposes the
+// full (loaded-HBM) read latency once per workgroup lifetime and has nothing in flight for that
+// workgroup while it computes.  Here a fixed grid of resident workgroups walks the tile list
+// (tile = block + k * grid: neighbouring workgroups still write neighbouring tiles) and keeps the
+// NEXT tile's 16-byte chunks in flight -- in registers -- while the current tile is blended,
+// colour-converted and stored; one LDS buffer, two barriers per tile.
+struct StageRegs {
+    uint4 y[2], uv[1];
+    bool oky[2], okuv[1];
+};
+struct TileCtx {
+    TileId id;
+    Footprint f;
+    LdsPlane py, puv;
+    const uint8_t *ay, *auv;
+    int ny, nuv, span_y, span_uv;
+};
+template <int MODE>
+__device__ __forceinline__ void tile_ctx(const LaunchDesc &d, const FrameTable &t, int tile, uint8_t *lds_y, uint8_t *lds_uv, TileCtx &c) {
+    const int tiles = d.tiles_x * d.tiles_y;
+    c.id.frame = tile / tiles;
+    const int rem = tile - c.id.frame * tiles;
+    c.id.ty = rem / d.tiles_x;
+    c.id.tx = rem - c.id.ty * d.tiles_x;
+    c.id.valid = true;
+    c.f = tile_footprint<MODE>(d, c.id);
+    c.py = describe_plane(lds_y, t.y[c.id.frame], d.pitch_y, c.f.ylo, c.f.xlo, d.lds_cpr_y, c.ay);
+    c.puv = describe_plane(lds_uv, t.uv[c.id.frame], d.pitch_uv, c.f.cylo, 2 * c.f.cxlo, d.lds_cpr_uv, c.auv);
+    c.ny = min(c.f.yhi - c.f.ylo + 1, d.lds_rows_y);
+    c.nuv = min(c.f.cyhi - c.f.cylo + 1, d.lds_rows_uv);
+    c.span_y = min(c.f.xhi - c.f.xlo + 1, d.lds_span_y);
+    c.span_uv = min(2 * (c.f.cxhi - c.f.cxlo + 1), d.lds_span_uv);
+}
+template <bool AREAUP, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    constexpr int MODE = AREAUP ? M_AREA_UP : M_BILINEAR;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const int total = d.tiles_x * d.tiles_y * d.n_frames;
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    XEntry *xtab = (XEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    XEntry *cxtab = xtab + tw;
+    YEntry *ytab = (YEntry *)(cxtab + (tw >> 1));
+    YEntry *cytab = ytab + th;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    const StageLane lny = stage_lane(d.lds_slot_y, nthreads), lnuv = stage_lane(d.lds_slot_uv, nthreads);
+    StageRegs R;
     {
-        const f2 wy = { cye.w, cye.w }, omy = (f2){ 1.0f, 1.0f } - wy;
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            // one address per row, taps at immediate offsets 0..3 (U0 V0 U1 V1); unaligned wide LDS
-            // reads are serialised by the hardware, so the taps are byte reads
-            const uint8_t *top = lds_uv + cye.top + cxe[c].off, *bot = lds_uv + cye.bot + cxe[c].off;
-            const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
-            const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
-            const f2 wx = { cxe[c].w, cxe[c].w }, omx = (f2){ 1.0f, 1.0f } - wx;
-            f2 sum = (A * omx) * omy + (B * wx) * omy;
-            sum = sum + (C * wy) * omx;
-            sum = sum + D * (wx * wy);
-            Uf[c] = __builtin_truncf(sum.x);
-            Vf[c] = __builtin_truncf(sum.y);
+        TileCtx c0;
+        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, c0);
+        stage_issue<2>(c0.ay, c0.py, d.pitch_y, c0.ny, c0.span_y, d.lds_cpr_y, lny, 0, R.y, R.oky);
+        stage_issue<1>(c0.auv, c0.puv, d.pitch_uv, c0.nuv, c0.span_uv, d.lds_cpr_uv, lnuv, 0, R.uv, R.okuv);
+    }
+    for (;;) {
+        TileCtx cur; // uniform: recomputed instead of carried across the loop
+        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, cur);
+        stage_commit<2>(lds_y, cur.py, lny, 0, R.y, R.oky); // waits for the chunks, writes them to LDS
+        stage_commit<1>(lds_uv, cur.puv, lnuv, 0, R.uv, R.okuv);
+        const Footprint &f = cur.f;
+        const LdsPlane &py = cur.py, &puv = cur.puv;
+        const int ntab = tw + (tw >> 1) + th + (th >> 1);
+        for (int e = threadIdx.x; e < ntab; e += nthreads) {
+            int p;
+            float w;
+            if (e < tw) {
+                axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
+                xtab[e] = XEntry{ p - f.xlo, w };
+            } else if (e < tw + (tw >> 1)) {
+                const int k = e - tw;
+                axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
+                cxtab[k] = XEntry{ 2 * (p - f.cxlo), w };
+            } else if (e < tw + (tw >> 1) + th) {
+                const int k = e - tw - (tw >> 1);
+                axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
+                const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo;
+                ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15), w, 0 };
+            } else {
+                const int k = e - tw - (tw >> 1) - th;
+                axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
+                const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
+                cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15), w, 0 };
+            }
         }
-    }
-    // luma: horizontally adjacent pixel pairs
-#pragma unroll
-    for (int r = 0; r < PXH; r++) {
-        const f2 wy = { ye[r].w, ye[r].w }, omy = (f2){ 1.0f, 1.0f } - wy;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const uint8_t *t0 = lds_y + ye[r].top + xe[2 * p].off, *t1 = lds_y + ye[r].top + xe[2 * p + 1].off;
-            const uint8_t *b0 = lds_y + ye[r].bot + xe[2 * p].off, *b1 = lds_y + ye[r].bot + xe[2 * p + 1].off;
-            const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
-            const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
-            const f2 wx = { xe[2 * p].w, xe[2 * p + 1].w }, omx = (f2){ 1.0f, 1.0f } - wx;
-            f2 sum = (A * omx) * omy + (B * wx) * omy;
-            sum = sum + (C * wy) * omx;
-            sum = sum + D * (wx * wy);
-            Yf[r][2 * p] = __builtin_truncf(sum.x);
-            Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
+        __syncthreads();
+        // next tile's chunks go in flight now and land while this tile is computed and stored
+        const int next = tile + (int)gridDim.x;
+        if (next < total) {
+            TileCtx nxt;
+            tile_ctx<MODE>(d, t, next, lds_y, lds_uv, nxt);
+            stage_issue<2>(nxt.ay, nxt.py, d.pitch_y, nxt.ny, nxt.span_y, d.lds_cpr_y, lny, 0, R.y, R.oky);
+            stage_issue<1>(nxt.auv, nxt.puv, d.pitch_uv, nxt.nuv, nxt.span_uv, d.lds_cpr_uv, lnuv, 0, R.uv, R.okuv);
         }
+        const bool edge_y = (f.xhi == d.src_w - 1), edge_uv = (f.cxhi == cw - 1);
+        if (edge_y || edge_uv) {
+            if (edge_y)
+                for (int r = threadIdx.x; r < cur.ny; r += nthreads) {
+                    uint8_t *q = lds_y + r * py.lp + ((py.m0 + r * py.pm) & 15) + (d.src_w - f.xlo);
+                    q[0] = q[-1];
+                }
+            if (edge_uv)
+                for (int r = threadIdx.x; r < cur.nuv; r += nthreads) {
+                    uint8_t *q = lds_uv + r * puv.lp + ((puv.m0 + r * puv.pm) & 15) + 2 * (cw - f.cxlo);
+                    q[0] = q[-2];
+                    q[1] = q[-1];
+                }
+            __syncthreads();
+        }
+        const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
+        if (j0 < d.dst_w && i0 < d.dst_h)
+            bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[cur.id.frame], i0, j0);
+        if (next >= total) break;
+        __syncthreads(); // everyone is done reading this tile's LDS before the next one overwrites it
+        tile = next;
     }
-    if (d.ablate & 1) { // profiling: keep the arithmetic alive without the HBM writes
-        float acc = Uf[0] + Vf[0] + Uf[1] + Vf[1];
-        for (int r = 0; r < PXH; r++)
-            for (int c = 0; c < PXW; c++) acc += Yf[r][c];
-        if (acc == -1.0f) ((float *)t.out[id.frame])[0] = acc;
-        return;
-    }
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -836,6 +1019,16 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
+            // persistent variant: needs <= 2 luma and <= 1 chroma staging rounds per thread
+            const int nthreads = d.tx * d.ty;
+            const bool fits = (2 * (nthreads >> d.lds_slot_y) >= d.lds_rows_y) && ((nthreads >> d.lds_slot_uv) >= d.lds_rows_uv);
+            if (d.persist > 0 && fits) {
+                const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
+                const long resident = (long)d.num_cus * d.persist;
+                dim3 pgrid((unsigned)(total < resident ? total : resident));
+                hipLaunchKernelGGL((vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, lds_bytes, stream, d, t);
+                return hipGetLastError();
+            }
             hipLaunchKernelGGL((vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes, stream, d, t);
             return hipGetLastError();
         }
@@ -921,6 +1114,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
     d.blocks_per_xcd = (int)((total + NUM_XCD - 1) / NUM_XCD);
+    if (d.tile_order == 0) { // whole tile rows per XCD: rows padded to a multiple of 8
+        const long rows = (long)d.tiles_y * d.n_frames;
+        d.blocks_per_xcd = (int)(((rows + NUM_XCD - 1) / NUM_XCD) * d.tiles_x);
+    }
     switch (mode) {
     case M_NONE: return launch_m<M_NONE>(out, vec, staged, d, t, lds_bytes, stream);
     case M_NEAREST: return launch_m<M_NEAREST>(out, vec, staged, d, t, lds_bytes, stream);
