@@ -142,6 +142,7 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     pl.out = f32 ? (p->planes == TSVPP_PLANAR ? O_F32_PLANAR : O_F32_MERGED)
                  : (p->planes == TSVPP_PLANAR ? O_U8_PLANAR : O_U8_MERGED);
     pl.out_bytes = (size_t)3 * (size_t)pl.dst_w * (size_t)pl.dst_h * (f32 ? sizeof(float) : 1);
+    if (pl.out_bytes >= ((size_t)1 << 32)) return TSVPP_UNSUPPORTED; // kernels use 32-bit offsets inside a frame
     return TSVPP_OK;
 }
 

@@ -331,7 +331,7 @@ __device__ __forceinline__ void st4(float *p, float a, float b, float c, float e
 // One output row of this thread: 4 pixels -> 3 channels, converted and stored.
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float t0[2], const float tg[2], const float t2[2],
-                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, size_t pix, size_t plane, int ncol, int nt) {
+                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, uint32_t pix, uint32_t plane, int ncol, int nt) {
     using T = typename OutT<OUT>::type;
     constexpr bool PLANAR = (OUT == O_U8_PLANAR || OUT == O_F32_PLANAR);
     f2 c0[2], c1[2], c2[2]; // channel values of pixel pairs (0,1) and (2,3)
@@ -356,11 +356,14 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
         float *o = (float *)out;
         if constexpr (VEC) {
             if constexpr (PLANAR) {
-                st4(o + pix, c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
-                st4(o + plane + pix, c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
-                st4(o + 2 * plane + pix, c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
+                // uniform plane bases (SGPR pairs) + one 32-bit byte offset per lane
+                const uint32_t boff = pix * 4u;
+                uint8_t *b0 = (uint8_t *)o, *b1 = (uint8_t *)(o + plane), *b2 = (uint8_t *)(o + 2 * (size_t)plane);
+                st4((float *)(b0 + boff), c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
+                st4((float *)(b1 + boff), c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
+                st4((float *)(b2 + boff), c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
             } else {
-                float *q = o + 3 * pix;
+                float *q = (float *)((uint8_t *)o + pix * 12u);
                 st4(q, c0[0].x, c1[0].x, c2[0].x, c0[0].y, nt);
                 st4(q + 4, c1[0].y, c2[0].y, c0[1].x, c1[1].x, nt);
                 st4(q + 8, c2[1].x, c0[1].y, c1[1].y, c2[1].y, nt);
@@ -419,10 +422,13 @@ __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const
     float t0[2], tg[2], t2[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
-    const size_t plane = (size_t)d.dst_w * (size_t)d.dst_h;
+    // 32-bit element offsets from the frame's (uniform) base pointer: the stores use the
+    // SGPR-base + VGPR-offset addressing mode instead of per-lane 64-bit pointer arithmetic
+    // (host side guarantees 3 * W * H * sizeof(T) < 4 GiB)
+    const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
 #pragma unroll
     for (int r = 0; r < PXH; r++)
-        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (size_t)(i0 + r) * (size_t)d.dst_w + (size_t)j0, plane, ncol, d.nt_stores);
+        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0, plane, ncol, d.nt_stores);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -704,6 +710,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
 
     // chroma: (U, V) of one block blended as a float pair
     float Uf[2], Vf[2], Yf[PXH][PXW];
+#ifdef TSVPP_ABLATION
     if (d.ablate & 4) { // profiling: staging + stores only
         for (int c = 0; c < 2; c++) Uf[c] = Vf[c] = (float)lds_uv[cye.top + cxe[c].off];
         for (int r = 0; r < PXH; r++)
@@ -721,6 +728,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
             for (int p = 0; p < 3; p++) st4(o + p * plane + (size_t)(i0 + r) * d.dst_w + j0, Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3], d.nt_stores);
         return;
     }
+#endif
     {
         const f2 wy = { cye.w, cye.w }, omy = (f2){ 1.0f, 1.0f } - wy;
 #pragma unroll
@@ -756,6 +764,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
             Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
         }
     }
+#ifdef TSVPP_ABLATION
     if (d.ablate & 1) { // profiling: keep the arithmetic alive without the HBM writes
         float acc = Uf[0] + Vf[0] + Uf[1] + Vf[1];
         for (int r = 0; r < PXH; r++)
@@ -763,6 +772,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
         if (acc == -1.0f) ((float *)out)[0] = acc;
         return;
     }
+#endif
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
@@ -788,10 +798,11 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-    if (!(d.ablate & 2)) {
+#ifdef TSVPP_ABLATION
+    if (!(d.ablate & 2))
+#endif
         stage_planes<2, 1>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
                            min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
-    }
 
     // coordinate tables (one entry per lane)
     const int ntab = tw + (tw >> 1) + th + (th >> 1);
