@@ -19,6 +19,7 @@
 
 #include "tsvpp.h"
 #include "vpp_kernels.h"
+#include "vpp_axis.h"
 
 using namespace tsvpp;
 
@@ -67,6 +68,33 @@ bool build_area_rows(float scale, std::vector<float> &tab, int &rows, int &taps)
     return rows > 0;
 }
 
+// Is every interpolation weight of this request zero?  (odd integer ratios; then BILINEAR and
+// BICUBIC reduce exactly to their centre tap, src/Resize.cu:17-23, 45-50 with w = 0)
+bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
+    // one-entry memo: a stream converts thousands of frames with the same geometry
+    struct Memo { int m, dw, dh, sw, sh; bool res; };
+    static thread_local Memo memo = { -1, 0, 0, 0, 0, false };
+    if (memo.m == (int)m && memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
+    auto remember = [&](bool r) { memo = Memo{ (int)m, dst_w, dst_h, src_w, src_h, r }; return r; };
+    for (int axis = 0; axis < 2; axis++) {
+        const int n = axis ? dst_h : dst_w, lim = axis ? src_h : src_w;
+        const float r = axis ? yr : xr;
+        for (int o = 0; o < n; o++) { // the chroma grid uses indices 0 .. n/2-1, a subset
+            int p;
+            if (m == M_BILINEAR) {
+                float w;
+                bilinear_axis(o, r, lim, p, w);
+                if (w != 0.0f) return remember(false);
+            } else {
+                double w;
+                bicubic_axis(o, r, lim, p, w);
+                if (w != 0.0) return remember(false);
+            }
+        }
+    }
+    return remember(true);
+}
+
 struct Plan {
     Mode mode = M_NONE;
     OutKind out = O_U8_MERGED;
@@ -76,6 +104,7 @@ struct Plan {
     float xr = 1.f, yr = 1.f;
     int swap_rb = 0;
     size_t out_bytes = 0;
+    int point_kind = PK_NONE;
 };
 
 } // namespace
@@ -132,6 +161,10 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
         default: return TSVPP_UNSUPPORTED; // reference launches nothing and returns garbage
         }
     }
+    pl.point_kind = PK_NONE;
+    if (pl.mode == M_NEAREST) pl.point_kind = PK_NEAREST;
+    else if ((pl.mode == M_BILINEAR || pl.mode == M_BICUBIC) && all_weights_zero(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h))
+        pl.point_kind = pl.mode == M_BILINEAR ? PK_BILINEAR0 : PK_BICUBIC0;
     switch (p->fourcc) {
     case TSVPP_RGB24: pl.swap_rb = 0; break;
     case TSVPP_BGR24: pl.swap_rb = 1; break;
@@ -329,6 +362,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.xr = pl.xr;
     d.yr = pl.yr;
     d.swap_rb = pl.swap_rb;
+    d.point_kind = pl.point_kind;
     d.k = ctx->coeffs;
     d.force_gather = ctx->force_gather;
     d.nt_stores = ctx->nt_stores;

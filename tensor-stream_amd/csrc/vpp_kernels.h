@@ -41,6 +41,7 @@ struct LaunchDesc {
     int lds_span_y, lds_rows_y, lds_cpr_y;
     int lds_span_uv, lds_rows_uv, lds_cpr_uv;
     int lds_slot_y, lds_slot_uv; // log2 of the lanes serving one staged row
+    int point_kind;   // PointKind: >= 0 when the request is a pure point sampler (host decides, see vpp_axis.h)
     int in_aligned4;  // every frame's (crop-adjusted) plane pointers and both pitches are multiples of 4
     int force_gather; // debugging / A-B: 1 = always use the global-gather kernel
     // tuning knobs (ctx options / TSVPP_* environment, see tsvpp_api.cpp)

@@ -14,6 +14,7 @@
 //
 // Written for wave64 / CDNA4 only; no other target is supported.
 #include "vpp_kernels.h"
+#include "vpp_axis.h"
 
 #pragma clang fp contract(off)
 
@@ -86,34 +87,6 @@ __device__ __forceinline__ int bilerp(int A, int B, int C, int D, float wx, floa
     s = s + t3;
     s = s + t4;
     return (int)s;
-}
-
-// Source coordinate + weight of one axis for BILINEAR (src/Resize.cu:276-303).
-__device__ __forceinline__ void bilinear_axis(int idx, float ratio, int limit, int &p, float &w) {
-    float f = ((float)idx + 0.5f) * ratio;
-    f = f - 0.5f;
-    p = (int)floorf(f);
-    w = f - (float)p;
-    if (p < 0) { p = 0; w = 0.f; }
-    if (p > limit - 1) { p = limit - 1; w = 0.f; }
-}
-// ... for the AREA up-scale variant (src/Resize.cu:221-234).
-__device__ __forceinline__ void areaup_axis(int idx, float ratio, int &p, float &w) {
-    p = (int)floorf(ratio * (float)idx);
-    float q = (float)(p + 1) / ratio;
-    float f = (float)(idx + 1) - q;
-    if (f <= 0.f) f = 0.f; else f = f - floorf(f);
-    w = f;
-}
-// ... for BICUBIC (src/Resize.cu:321-347): fp32 coordinate widened to double.
-__device__ __forceinline__ void bicubic_axis(int idx, float ratio, int limit, int &p, double &w) {
-    float ff = ((float)idx + 0.5f) * ratio;
-    ff = ff - 0.5f;
-    double f = (double)ff;
-    p = (int)floor(f);
-    w = f - (double)p;
-    if (p < 0) { p = 0; w = 0.0; }
-    if (p > limit - 1) { p = limit - 1; w = 0.0; }
 }
 
 // Keys cubic, a = -0.75 (src/Resize.cu:45-50).  pow(w,2), pow(w,3) are the exact square and the
@@ -977,6 +950,86 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
 }
 
 // ----------------------------------------------------------------------------------------------
+// Point-sampling kernel: NEAREST, and BILINEAR / BICUBIC requests whose weights are all zero.
+// Every output row needs exactly ONE source row and every output column one source byte (pair),
+// so only those rows are staged -- a 3x down-scale reads a third of the luma plane -- one LDS row
+// per output row, and a tap is a single LDS byte read through small per-tile offset tables.
+template <int KIND, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_point_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const int j_first = id.tx * tw, i_first = id.ty * th;
+    const int j_last = min(j_first + tw, d.dst_w) - 1, i_last = min(i_first + th, d.dst_h) - 1;
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+    // column extent of the tile in both planes (coordinates are monotonic in the output index)
+    const int xlo = min(max(point_coord<KIND>(j_first, d.xr, d.src_w), 0), d.src_w - 1);
+    const int xhi = min(max(point_coord<KIND>(j_last, d.xr, d.src_w), 0), d.src_w - 1);
+    const int cxlo = min(max(point_coord<KIND>(j_first >> 1, d.xr, d.src_w), 0), cw - 1);
+    const int cxhi = min(max(point_coord<KIND>(j_last >> 1, d.xr, d.src_w), 0), cw - 1);
+    const int span_y = min(xhi - xlo + 1, d.lds_span_y), span_uv = min(2 * (cxhi - cxlo + 1), d.lds_span_uv);
+    const int ny = i_last - i_first + 1, nuv = (i_last >> 1) - (i_first >> 1) + 1;
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + th * d.lds_cpr_y * 16;
+    int *xtab = (int *)(lds_uv + (th >> 1) * d.lds_cpr_uv * 16);
+    int *cxtab = xtab + tw;
+    int *ytab = cxtab + (tw >> 1); // LDS byte offset of each staged luma row (incl. its misalignment)
+    int *cytab = ytab + th;
+
+    // stage: luma row r <- source row y(i_first + r); chroma row r <- source row y(ci_first + r)
+    {
+        const StageLane ln = stage_lane(d.lds_slot_y, nthreads);
+        const int lp = 16 * d.lds_cpr_y;
+        for (int r = ln.r0; r < ny; r += ln.rstep) {
+            const int y = min(max(point_coord<KIND>(i_first + r, d.yr, d.src_h), 0), d.src_h - 1);
+            const uint8_t *a = t.y[id.frame] + (size_t)y * (size_t)d.pitch_y + (size_t)xlo;
+            const int mis = (int)((uintptr_t)a & 15);
+            if (ln.ch == 0) ytab[r] = r * lp + mis;
+            if (ln.ch < d.lds_cpr_y && 16 * ln.ch < mis + span_y) *(uint4 *)(lds_y + r * lp + 16 * ln.ch) = *(const uint4 *)(a - mis + 16 * ln.ch);
+        }
+    }
+    {
+        const StageLane ln = stage_lane(d.lds_slot_uv, nthreads);
+        const int lp = 16 * d.lds_cpr_uv;
+        for (int r = ln.r0; r < nuv; r += ln.rstep) {
+            const int y = min(max(point_coord<KIND>((i_first >> 1) + r, d.yr, d.src_h), 0), chh - 1);
+            const uint8_t *a = t.uv[id.frame] + (size_t)y * (size_t)d.pitch_uv + (size_t)(2 * cxlo);
+            const int mis = (int)((uintptr_t)a & 15);
+            if (ln.ch == 0) cytab[r] = r * lp + mis;
+            if (ln.ch < d.lds_cpr_uv && 16 * ln.ch < mis + span_uv) *(uint4 *)(lds_uv + r * lp + 16 * ln.ch) = *(const uint4 *)(a - mis + 16 * ln.ch);
+        }
+    }
+    for (int e = threadIdx.x; e < tw + (tw >> 1); e += nthreads) {
+        if (e < tw) xtab[e] = min(max(point_coord<KIND>(j_first + e, d.xr, d.src_w), 0), d.src_w - 1) - xlo;
+        else cxtab[e - tw] = 2 * (min(max(point_coord<KIND>((j_first >> 1) + e - tw, d.xr, d.src_w), 0), cw - 1) - cxlo);
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = j_first + lx * PXW, i0 = i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const int4 xo = *(const int4 *)(xtab + lx * PXW);
+    const int2 cxo = *(const int2 *)(cxtab + lx * 2);
+    const int2 yo = *(const int2 *)(ytab + ly * PXH);
+    const int cyo = cytab[ly];
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    const uint8_t *cr = lds_uv + cyo;
+    Uf[0] = (float)cr[cxo.x];
+    Vf[0] = (float)cr[cxo.x + 1];
+    Uf[1] = (float)cr[cxo.y];
+    Vf[1] = (float)cr[cxo.y + 1];
+    const int xs[PXW] = { xo.x, xo.y, xo.z, xo.w }, ys[PXH] = { yo.x, yo.y };
+#pragma unroll
+    for (int r = 0; r < PXH; r++)
+#pragma unroll
+        for (int c = 0; c < PXW; c++) Yf[r][c] = (float)lds_y[ys[r] + xs[c]];
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Colour-only kernel (no resize; crop is already folded into the pointers): thread = 2 rows x 4
 // pixels, 4-byte coalesced luma loads, one 4-byte chroma load (2 pairs) shared by the two rows.
 // Every store instruction of a wave covers one contiguous run (lane stride 16 B): two 16-byte
@@ -1025,9 +1078,23 @@ static int slot_shift_for(int cpr) {
     return s;
 }
 
+template <int OUT>
+static hipError_t launch_point(const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream) {
+    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
+    switch (d.point_kind) {
+    case PK_NEAREST: hipLaunchKernelGGL((vpp_point_kernel<PK_NEAREST, OUT>), grid, block, lds_bytes, stream, d, t); break;
+    case PK_BILINEAR0: hipLaunchKernelGGL((vpp_point_kernel<PK_BILINEAR0, OUT>), grid, block, lds_bytes, stream, d, t); break;
+    case PK_BICUBIC0: hipLaunchKernelGGL((vpp_point_kernel<PK_BICUBIC0, OUT>), grid, block, lds_bytes, stream, d, t); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int MODE, int OUT>
 static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
+    if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
+        return launch_point<OUT>(d, t, lds_bytes, stream);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
             // persistent variant: needs <= 2 luma and <= 1 chroma staging rounds per thread
@@ -1088,7 +1155,35 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     size_t lds_bytes = 0;
     d.tx = shapes[0][0];
     d.ty = shapes[0][1];
-    if (mode != M_NONE && vec && !d.force_gather) {
+    const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
+    if (!point) d.point_kind = PK_NONE;
+    if (point && vec && !d.force_gather) {
+        for (auto &sh : shapes) {
+            if (sh[0] == 0) break;
+            const int tw = sh[0] * PXW, th = sh[1] * PXH, nthreads = sh[0] * sh[1];
+            const int span_y = (int)((double)d.xr * (tw - 1)) + 3, span_uv = 2 * ((int)((double)d.xr * (tw / 2 - 1)) + 3);
+            const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
+            if (cpr_y > nthreads || cpr_uv > nthreads) continue;
+            const size_t need = (size_t)16 * ((size_t)th * cpr_y + (size_t)(th / 2) * cpr_uv) + sizeof(int) * (size_t)(tw + tw / 2 + th + th / 2);
+            if (need <= kLdsBudget) {
+                staged = true;
+                lds_bytes = need;
+                d.tx = sh[0];
+                d.ty = sh[1];
+                d.lds_span_y = span_y;
+                d.lds_cpr_y = cpr_y;
+                d.lds_slot_y = slot_shift_for(cpr_y);
+                d.lds_span_uv = span_uv;
+                d.lds_cpr_uv = cpr_uv;
+                d.lds_slot_uv = slot_shift_for(cpr_uv);
+                break;
+            }
+        }
+        if (!staged) d.point_kind = PK_NONE; // footprint too large: generic paths below
+    } else {
+        d.point_kind = PK_NONE;
+    }
+    if (!staged && mode != M_NONE && vec && !d.force_gather) {
         for (auto &sh : shapes) {
             if (sh[0] == 0) break;
             const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);

@@ -206,6 +206,18 @@ def test_staging_shapes(vpp, oracle, rt, src, dst):
     check(vpp, oracle, y, uv, dst=dst, resize_type=rt, fourcc=BGR24, planes=PLANAR, normalization=False)
 
 
+@pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC])
+@pytest.mark.parametrize("src,dst", [((1920, 1080), (640, 360)),     # ratio 3: all weights zero -> point-sampling kernel
+                                     ((3840, 2160), (768, 432)),     # ratio 5
+                                     ((1920, 1080), (384, 360)),     # 5 x 3
+                                     ((1282, 722), (428, 242))])     # ~2.995: NOT zero-weight -> interpolating kernels
+def test_point_sampling_kernel(vpp, oracle, rt, src, dst):
+    y, uv = synth_nv12(src[0], src[1], seed=rt * 13 + dst[0], pitch=src[0] + 6)
+    check(vpp, oracle, y, uv, width=src[0], dst=dst, resize_type=rt, fourcc=BGR24, planes=MERGED, normalization=False)
+    check(vpp, oracle, y, uv, width=src[0], crop=(2, 2, src[0] - 2, src[1] - 2), dst=dst, resize_type=rt, fourcc=RGB24, planes=PLANAR,
+          normalization=True)
+
+
 def test_consumer_pool_semantics(vpp):
     """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
     (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
