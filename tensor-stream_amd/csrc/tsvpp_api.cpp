@@ -28,7 +28,34 @@ namespace {
 struct AreaTable {
     float *dev = nullptr;
     int rows = 0, taps = 0;
+    AreaQRow *qdev = nullptr; // integer form, only if every weight is k / 2^shift and taps <= 8
+    int shift = -1;
 };
+
+// Integer form of a weight table if all weights are dyadic: w * 2^shift integral, shift <= 6.
+bool quantise_area_rows(const std::vector<float> &tab, int rows, int taps, std::vector<AreaQRow> &q, int &shift) {
+    if (taps > 8) return false;
+    for (shift = 0; shift <= 6; shift++) {
+        bool ok = true;
+        for (float w : tab) {
+            const float s = w * (float)(1 << shift);
+            if (s != std::floor(s) || s > 255.0f) { ok = false; break; }
+        }
+        if (ok) break;
+    }
+    if (shift > 6) return false;
+    q.assign((size_t)rows, AreaQRow{});
+    for (int r = 0; r < rows; r++) {
+        AreaQRow &e = q[(size_t)r];
+        for (int k = 0; k < taps; k++) {
+            const uint32_t wi = (uint32_t)(tab[(size_t)r * taps + k] * (float)(1 << shift));
+            e.sum += (int32_t)wi;
+            e.w[k >> 2] |= wi << (8 * (k & 3));
+            e.wu[k >> 1] |= wi << (16 * (k & 1));
+        }
+    }
+    return true;
+}
 
 constexpr int kMaxPatternRows = 65536; // the reference's generator has no bound (can spin forever)
 
@@ -198,6 +225,14 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
         (void)hipFree(t.dev);
         return (int)e;
     }
+    std::vector<AreaQRow> q;
+    if (quantise_area_rows(tab, t.rows, t.taps, q, t.shift)) {
+        if (hipMalloc((void **)&t.qdev, q.size() * sizeof(AreaQRow)) == hipSuccess &&
+            hipMemcpy(t.qdev, q.data(), q.size() * sizeof(AreaQRow), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(t.qdev);
+            t.qdev = nullptr;
+        }
+    }
     ctx->area[key] = t;
     out = t;
     return TSVPP_OK;
@@ -270,8 +305,10 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
     (void)ensure_device(ctx);
     for (auto &s : ctx->streams)
         if (s.second) (void)hipStreamDestroy(s.second);
-    for (auto &a : ctx->area)
+    for (auto &a : ctx->area) {
         if (a.second.dev) (void)hipFree(a.second.dev);
+        if (a.second.qdev) (void)hipFree(a.second.qdev);
+    }
     delete ctx;
 }
 
@@ -384,6 +421,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.paty = ty.dev;
         d.ny = ty.rows;
         d.ry = ty.taps;
+        // integer box sums are exact (and equal to the reference's float accumulation) while
+        // 255 * sum(wx) * sum(wy) stays below 2^24
+        if (tx.qdev && ty.qdev && (double)255 * ((double)pl.xr * (1 << tx.shift) + 1) * ((double)pl.yr * (1 << ty.shift) + 1) < 16777216.0) {
+            d.qx = tx.qdev;
+            d.qy = ty.qdev;
+        }
     }
     // crop = pointer arithmetic (reference src/Crop.cu:10-18: luma at (left + j, top + i), chroma
     // row top/2 + i/2, chroma byte (j & ~1) + left -- an odd `left` therefore swaps U and V,

@@ -21,6 +21,17 @@ struct FrameTable {
     void *out[TSVPP_MAX_BATCH];
 };
 
+// One row of an AREA weight table quantised to integers (weights * 2^shift), for requests whose
+// weights are all dyadic (integer ratios, 1.5, 2.25, ...): then every partial sum of the
+// reference's float accumulation is exact, the summation order is irrelevant, and the weighted box
+// sum can be taken with v_dot4_u32_u8 on packed bytes.
+struct AreaQRow {
+    int32_t sum;     // sum of the integer weights of the row
+    uint32_t w[2];   // weights 0..7 packed as bytes (luma taps; also the vertical weights)
+    uint32_t wu[4];  // the same weights spread over even bytes: (w0,0,w1,0) ... for interleaved U,V
+    int32_t pad;
+};
+
 struct LaunchDesc {
     // logical source = the crop box if crop is active, else the whole frame; the frame
     // pointers in FrameTable are already advanced to its top-left corner
@@ -33,6 +44,7 @@ struct LaunchDesc {
     // AREA-down weight tables: nx rows of rx floats, ny rows of ry floats (rx = ceil(xr))
     const float *patx, *paty;
     int nx, ny, rx, ry;
+    const AreaQRow *qx, *qy; // non-null: dyadic AREA tables (integer box sums)
     // grid decomposition (filled by launch_fused)
     int tiles_x, tiles_y, n_frames;
     int blocks_per_xcd; // ceil(total_tiles / 8)

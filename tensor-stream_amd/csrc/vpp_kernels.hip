@@ -950,6 +950,149 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
 }
 
 // ----------------------------------------------------------------------------------------------
+// AREA down-scale with dyadic weights (integer ratios -> all ones; 1.5 -> {1,.5}; 2.25 -> quarters...).
+// The reference accumulates float(data) * (wx*wy) tap by tap (src/Resize.cu:160-178); when every
+// weight is k / 2^s all partial sums are exactly representable, so the result equals
+// (int)( float(SUM) / float(SX*SY) ) with SUM = sum_a wy[a] * sum_b wx[b] * p[a][b] in integers --
+// and the inner sum over four packed source bytes is ONE v_dot4_u32_u8.  The box starts at an
+// arbitrary byte: v_alignbyte_b32 shifts the aligned LDS dwords so that tap 0 sits in byte 0.
+struct AXEntry { int off, sum; uint32_t w0, w1; };                // luma column: LDS offset, sum(wx), packed weights
+struct ACEntry { int off, sum; uint32_t wu[4]; int pad0, pad1; }; // chroma pair column: weights on even bytes
+struct AYEntry { int row, sum; uint32_t w0, w1; };                // output row: first staged row, sum(wy), packed weights
+
+template <int NW, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const Footprint f = tile_footprint<M_AREA_DOWN>(d, id);
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    AXEntry *xtab = (AXEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    ACEntry *cxtab = (ACEntry *)(xtab + tw);
+    AYEntry *ytab = (AYEntry *)(cxtab + (tw >> 1));
+    AYEntry *cytab = ytab + th;
+    int *rby = (int *)(cytab + (th >> 1)); // LDS byte offset of every staged luma row (incl. misalignment)
+    int *rbuv = rby + d.lds_rows_y;
+
+    const uint8_t *ay, *auv;
+    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
+    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    // small workgroups (large footprints) must keep many chunks per lane in flight, or the staging
+    // is latency-bound: 64 threads -> 16 + 8 chunks per lane, 256 threads -> 4 + 2
+    if (nthreads <= 64)
+        stage_planes<16, 8>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
+                            min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    else if (nthreads <= 128)
+        stage_planes<8, 4>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
+                           min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    else
+        stage_planes<4, 2>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
+                           min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    const int ntab = tw + (tw >> 1) + th + (th >> 1) + d.lds_rows_y + d.lds_rows_uv;
+    for (int e = threadIdx.x; e < ntab; e += nthreads) {
+        int k = e;
+        if (k < tw) {
+            const int j = f.j_first + k;
+            const AreaQRow q = d.qx[j % d.nx];
+            xtab[k] = AXEntry{ (int)(d.xr * (float)j) - f.xlo, q.sum, q.w[0], q.w[1] };
+            continue;
+        }
+        k -= tw;
+        if (k < (tw >> 1)) {
+            const int cj = (f.j_first >> 1) + k;
+            const AreaQRow q = d.qx[cj % d.nx];
+            cxtab[k] = ACEntry{ 2 * ((int)(d.xr * (float)cj) - f.cxlo), q.sum, { q.wu[0], q.wu[1], q.wu[2], q.wu[3] }, 0, 0 };
+            continue;
+        }
+        k -= tw >> 1;
+        if (k < th) {
+            const int i = f.i_first + k;
+            const AreaQRow q = d.qy[i % d.ny];
+            ytab[k] = AYEntry{ (int)(d.yr * (float)i) - f.ylo, q.sum, q.w[0], q.w[1] };
+            continue;
+        }
+        k -= th;
+        if (k < (th >> 1)) {
+            const int ci = (f.i_first >> 1) + k;
+            const AreaQRow q = d.qy[ci % d.ny];
+            cytab[k] = AYEntry{ (int)(d.yr * (float)ci) - f.cylo, q.sum, q.w[0], q.w[1] };
+            continue;
+        }
+        k -= th >> 1;
+        if (k < d.lds_rows_y) rby[k] = k * py.lp + ((py.m0 + k * py.pm) & 15);
+        else { k -= d.lds_rows_y; rbuv[k] = k * puv.lp + ((puv.m0 + k * puv.pm) & 15); }
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    { // chroma: U on even bytes, V on odd bytes of the same dwords
+        const AYEntry ye = cytab[ly];
+        uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
+        ACEntry ce[2] = { cxtab[lx * 2], cxtab[lx * 2 + 1] };
+        for (int a = 0; a < d.ry; a++) {
+            const uint32_t wy = ((a < 4 ? ye.w0 : ye.w1) >> (8 * (a & 3))) & 255u;
+            const int rb = rbuv[ye.row + a];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int A = rb + ce[c].off;
+                const uint32_t *p = (const uint32_t *)(lds_uv + (A & ~3));
+                const uint32_t sh = (uint32_t)A & 3u;
+                uint32_t ru = 0, rv = 0;
+#pragma unroll
+                for (int k = 0; k < 2 * NW; k++) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(p[k + 1], p[k], sh);
+                    ru = __builtin_amdgcn_udot4(v, ce[c].wu[k], ru, false);
+                    rv = __builtin_amdgcn_udot4(v, ce[c].wu[k] << 8, rv, false);
+                }
+                su[c] += wy * ru;
+                sv[c] += wy * rv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float div = (float)(ce[c].sum * ye.sum);
+            Uf[c] = __builtin_truncf((float)su[c] / div);
+            Vf[c] = __builtin_truncf((float)sv[c] / div);
+        }
+    }
+    {
+        AXEntry xe[PXW];
+#pragma unroll
+        for (int c = 0; c < PXW; c++) xe[c] = xtab[lx * PXW + c];
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const AYEntry ye = ytab[ly * PXH + r];
+            uint32_t sum[PXW] = { 0, 0, 0, 0 };
+            for (int a = 0; a < d.ry; a++) {
+                const uint32_t wy = ((a < 4 ? ye.w0 : ye.w1) >> (8 * (a & 3))) & 255u;
+                const int rb = rby[ye.row + a];
+#pragma unroll
+                for (int c = 0; c < PXW; c++) {
+                    const int A = rb + xe[c].off;
+                    const uint32_t *p = (const uint32_t *)(lds_y + (A & ~3));
+                    const uint32_t sh = (uint32_t)A & 3u;
+                    uint32_t rs = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(p[1], p[0], sh), xe[c].w0, 0u, false);
+                    if constexpr (NW == 2) rs = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(p[2], p[1], sh), xe[c].w1, rs, false);
+                    sum[c] += wy * rs;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < PXW; c++) Yf[r][c] = __builtin_truncf((float)sum[c] / (float)(xe[c].sum * ye.sum));
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Point-sampling kernel: NEAREST, and BILINEAR / BICUBIC requests whose weights are all zero.
 // Every output row needs exactly ONE source row and every output column one source byte (pair),
 // so only those rows are staged -- a 3x down-scale reads a third of the luma plane -- one LDS row
@@ -1111,6 +1254,13 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             return hipGetLastError();
         }
     } else if constexpr (MODE != M_NONE) {
+        if constexpr (MODE == M_AREA_DOWN) {
+            if (staged && d.qx && d.qy) {
+                if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, OUT>), grid, block, lds_bytes, stream, d, t);
+                else hipLaunchKernelGGL((vpp_area_dyadic_kernel<2, OUT>), grid, block, lds_bytes, stream, d, t);
+                return hipGetLastError();
+            }
+        }
         if (staged) {
             hipLaunchKernelGGL((vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes, stream, d, t);
             return hipGetLastError();
@@ -1194,6 +1344,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             const int nthreads = sh[0] * sh[1];
             if (cpr_y > nthreads || cpr_uv > nthreads) continue;
             size_t need = (size_t)16 * ((size_t)rows_y * cpr_y + (size_t)rows_uv * cpr_uv);
+            if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
+                need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
+                        (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_y + rows_uv) + 32;
             if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
                 need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
             if (need <= kLdsBudget) {

@@ -218,6 +218,23 @@ def test_point_sampling_kernel(vpp, oracle, rt, src, dst):
           normalization=True)
 
 
+@pytest.mark.parametrize("src,dst", [((1440, 810), (640, 360)),    # 2.25: quarter weights
+                                     ((1600, 900), (640, 360)),    # 2.5
+                                     ((2560, 1440), (640, 360)),   # 4: all ones, one weight dword
+                                     ((960, 540), (128, 72)),      # 7.5: eight taps
+                                     ((1024, 576), (128, 72)),     # 8
+                                     ((800, 450), (640, 360)),     # 1.25
+                                     ((1920, 1080), (1280, 360)),  # 1.5 x 3
+                                     ((1922, 1082), (1281 + 1, 722))])  # non-dyadic neighbour of 1.5 -> generic float path
+def test_area_dyadic_integer_kernel(vpp, oracle, src, dst):
+    """AREA down-scales whose weights are all k/2^s run on integer box sums (v_dot4_u32_u8); must equal the
+    reference's float accumulation bit for bit."""
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0], pitch=src[0] + 10)
+    check(vpp, oracle, y, uv, width=src[0], dst=dst, resize_type=AREA, fourcc=BGR24, planes=PLANAR, normalization=True)
+    check(vpp, oracle, y, uv, width=src[0], crop=(3, 2, src[0] - 1, src[1] - 2) if (src[0] - 4) % 2 == 0 else (0, 0, 0, 0), dst=dst,
+          resize_type=AREA, fourcc=RGB24, planes=MERGED, normalization=False)
+
+
 def test_consumer_pool_semantics(vpp):
     """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
     (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
