@@ -132,6 +132,8 @@ struct Plan {
     int swap_rb = 0;
     size_t out_bytes = 0;
     int point_kind = PK_NONE;
+    int fourcc = TSVPP_RGB24;
+    bool f32 = false;
 };
 
 } // namespace
@@ -147,6 +149,9 @@ struct tsvpp_ctx {
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
     std::mutex area_mu;
+    // NV12 intermediates for the two-pass formats, one grow-only buffer per stream
+    std::map<void *, std::pair<uint8_t *, size_t>> scratch;
+    std::mutex scratch_mu;
 };
 
 namespace {
@@ -192,16 +197,23 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     if (pl.mode == M_NEAREST) pl.point_kind = PK_NEAREST;
     else if ((pl.mode == M_BILINEAR || pl.mode == M_BICUBIC) && all_weights_zero(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h))
         pl.point_kind = pl.mode == M_BILINEAR ? PK_BILINEAR0 : PK_BICUBIC0;
+    pl.fourcc = p->fourcc;
     switch (p->fourcc) {
     case TSVPP_RGB24: pl.swap_rb = 0; break;
     case TSVPP_BGR24: pl.swap_rb = 1; break;
+    case TSVPP_Y800: case TSVPP_NV12: case TSVPP_UYVY: case TSVPP_YUV444: case TSVPP_HSV: break; // via the NV12 intermediate
     default: return TSVPP_UNSUPPORTED;
     }
     if (p->planes != TSVPP_PLANAR && p->planes != TSVPP_MERGED) return TSVPP_UNSUPPORTED;
-    const bool f32 = p->normalization != 0; // src/VideoProcessor.cpp:139-142
+    // element type: src/VideoProcessor.cpp:139-142; HSV always runs the float kernels (src/ColorConversion.cu:357-370)
+    const bool f32 = p->normalization != 0 || p->fourcc == TSVPP_HSV;
+    pl.f32 = f32;
     pl.out = f32 ? (p->planes == TSVPP_PLANAR ? O_F32_PLANAR : O_F32_MERGED)
                  : (p->planes == TSVPP_PLANAR ? O_U8_PLANAR : O_U8_MERGED);
-    pl.out_bytes = (size_t)3 * (size_t)pl.dst_w * (size_t)pl.dst_h * (f32 ? sizeof(float) : 1);
+    // channelsByFourCC: 1.5 for NV12 (src/VideoProcessor.cpp:4-14)
+    const size_t elems = p->fourcc == TSVPP_NV12 ? (size_t)pl.dst_w * pl.dst_h * 3 / 2
+                                                 : (size_t)(tsvpp_channels(p->fourcc) * (float)pl.dst_w) * (size_t)pl.dst_h;
+    pl.out_bytes = elems * (f32 ? sizeof(float) : 1);
     if (pl.out_bytes >= ((size_t)1 << 32)) return TSVPP_UNSUPPORTED; // kernels use 32-bit offsets inside a frame
     return TSVPP_OK;
 }
@@ -305,6 +317,8 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
     (void)ensure_device(ctx);
     for (auto &s : ctx->streams)
         if (s.second) (void)hipStreamDestroy(s.second);
+    for (auto &sc : ctx->scratch)
+        if (sc.second.first) (void)hipFree(sc.second.first);
     for (auto &a : ctx->area) {
         if (a.second.dev) (void)hipFree(a.second.dev);
         if (a.second.qdev) (void)hipFree(a.second.qdev);
@@ -437,13 +451,38 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     for (int f = 0; f < n && aligned4; f++)
         aligned4 = (((uintptr_t)(in[f].y + y_off)) % 4 == 0) && (((uintptr_t)(in[f].uv + uv_off)) % 4 == 0);
     d.in_aligned4 = aligned4 ? 1 : 0;
-    for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
+    // Formats other than RGB24/BGR24: the reference feeds its other colour kernels with
+    // the resized NV12; here pass 1 (only if there is a resize) writes that intermediate with the
+    // fused kernel, pass 2 converts it.  Crop alone needs no pass 1: it is pointer arithmetic.
+    const bool two_pass = pl.fourcc != TSVPP_RGB24 && pl.fourcc != TSVPP_BGR24;
+    uint8_t *scratch = nullptr;
+    size_t frame_scratch = 0;
+    if (two_pass && pl.mode != M_NONE) {
+        frame_scratch = (((size_t)pl.dst_w * pl.dst_h * 3 / 2) + 255) & ~(size_t)255;
+        const size_t need = frame_scratch * (size_t)n;
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        auto &slot = ctx->scratch[stream];
+        if (slot.second < need) { // grow-only; hipFree synchronises, so the old buffer is idle when released
+            if (slot.first) (void)hipFree(slot.first);
+            slot = { nullptr, 0 };
+            hipError_t e = hipMalloc((void **)&slot.first, need);
+            if (e != hipSuccess) return (int)e;
+            slot.second = need;
+        }
+        scratch = slot.first;
+    }
+    OutKind out_kind = pl.out;
+    if (two_pass) {
+        out_kind = O_NV12_U8;
+        vec = (pl.dst_w % 4) == 0; // scratch frames are 256-byte aligned
+    }
+    for (int base = 0; base < n && !(two_pass && pl.mode == M_NONE); base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
         FrameTable t;
         for (int f = 0; f < cnt; f++) {
             t.y[f] = in[base + f].y + y_off;
             t.uv[f] = in[base + f].uv + uv_off;
-            t.out[f] = outs[base + f];
+            t.out[f] = two_pass ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
         }
         for (int f = cnt; f < TSVPP_MAX_BATCH; f++) {
             t.y[f] = nullptr;
@@ -451,8 +490,27 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
             t.out[f] = nullptr;
         }
         d.n_frames = cnt;
-        hipError_t e = launch_fused(pl.mode, pl.out, vec, d, t, (hipStream_t)stream);
+        hipError_t e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
+    }
+    if (two_pass) {
+        for (int f = 0; f < n; f++) {
+            const uint8_t *fy, *fuv;
+            int fpy, fpuv;
+            if (pl.mode != M_NONE) { // resized intermediate: tight, pitch = width (as the reference's)
+                fy = scratch + (size_t)f * frame_scratch;
+                fuv = fy + (size_t)pl.dst_w * pl.dst_h;
+                fpy = fpuv = pl.dst_w;
+            } else {
+                fy = in[f].y + y_off;
+                fuv = in[f].uv + uv_off;
+                fpy = pitch_y;
+                fpuv = pitch_uv;
+            }
+            hipError_t e = launch_format(pl.fourcc, pl.f32, p->normalization != 0 || pl.fourcc == TSVPP_HSV, fy, fuv, fpy, fpuv, pl.dst_w,
+                                         pl.dst_h, outs[f], ctx->coeffs, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     return TSVPP_OK;
 }

@@ -66,10 +66,16 @@ struct LaunchDesc {
 };
 
 // Output flavour: element type x layout.
-enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_COUNT };
+// O_NV12_U8: the resized NV12 itself (Y plane then interleaved UV plane, tight) -- the intermediate the
+// reference hands to its other colour kernels; feeds vpp_formats.hip.
+enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_COUNT };
 
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
 // store path (needs dst_w % 4 == 0 and 16-byte aligned outputs).  Returns hipError_t.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream);
+
+// Y800 / NV12 / UYVY / YUV444 / HSV from one NV12 frame (vpp_formats.hip).
+hipError_t launch_format(int fourcc, bool f32, bool norm, const uint8_t *y, const uint8_t *uv, int py, int puv, int w, int h, void *out,
+                         const tsvpp_coeffs &k, hipStream_t stream);
 
 } // namespace tsvpp

@@ -392,6 +392,28 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
                                                  typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
+    if constexpr (OUT == O_NV12_U8) { // no colour conversion: the resized NV12 intermediate itself
+        uint8_t *o = (uint8_t *)out;
+        const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+            if constexpr (VEC) *(uchar4 *)(o + pix) = make_uchar4((uint8_t)Yf[r][0], (uint8_t)Yf[r][1], (uint8_t)Yf[r][2], (uint8_t)Yf[r][3]);
+            else
+                for (int c = 0; c < ncol; c++) o[pix + c] = (uint8_t)Yf[r][c];
+        }
+        const uint32_t cpix = plane + (uint32_t)(i0 >> 1) * (uint32_t)d.dst_w + (uint32_t)j0;
+        if constexpr (VEC) *(uchar4 *)(o + cpix) = make_uchar4((uint8_t)Uf[0], (uint8_t)Vf[0], (uint8_t)Uf[1], (uint8_t)Vf[1]);
+        else {
+            o[cpix] = (uint8_t)Uf[0];
+            o[cpix + 1] = (uint8_t)Vf[0];
+            if (ncol > 2) {
+                o[cpix + 2] = (uint8_t)Uf[1];
+                o[cpix + 3] = (uint8_t)Vf[1];
+            }
+        }
+        return;
+    }
     float t0[2], tg[2], t2[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
@@ -1285,6 +1307,7 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
     case O_U8_MERGED: return launch_mo<MODE, O_U8_MERGED>(vec, staged, d, t, lds, stream);
     case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, staged, d, t, lds, stream);
     case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, staged, d, t, lds, stream);
+    case O_NV12_U8: return launch_mo<MODE, O_NV12_U8>(vec, staged, d, t, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

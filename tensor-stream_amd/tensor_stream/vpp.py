@@ -117,7 +117,7 @@ class VideoProcessor:
     def _alloc(self, p, in_w, in_h, n=None):
         ow, oh = self.out_dims(p, in_w, in_h)
         shape = output_shape(p, ow, oh)
-        dtype = torch.float32 if p.normalization else torch.uint8
+        dtype = torch.float32 if (p.normalization or p.fourcc == FourCC.HSV.value) else torch.uint8
         if n is not None:
             shape = (n,) + tuple(shape)
         return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
