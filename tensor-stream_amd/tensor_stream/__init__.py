@@ -5,4 +5,6 @@ putting `tensor-stream_amd/` on sys.path.
 """
 from .vpp import FourCC, FrameParameters, Planes, ResizeType, VideoProcessor, default_coeffs, output_shape  # noqa: F401
 
+from .tensor_stream import FrameRate, FrameRing, LogsLevel, LogsType, StatusLevel, TensorStreamConverter  # noqa: F401
+
 __version__ = "0.1.0"

@@ -135,10 +135,14 @@ class VideoProcessor:
         fr = self._frame(y, uv, width, height)
         if out is None:
             out = self._alloc(p, fr.width, fr.height)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device)
+        stream = cur.cuda_stream
+        ext = None
         if consumer is not None:
-            stream = self._on_consumer_stream(consumer)
+            stream, ext = self._on_consumer_stream(consumer)
         N.check(self._lib.tsvpp_convert(self._ctx, ctypes.byref(fr), ctypes.byref(p), out.data_ptr(), stream))
+        if ext is not None:
+            cur.wait_stream(ext)  # later work on torch's stream sees the finished tensor (no host sync)
         return out
 
     convert = Convert
@@ -177,7 +181,7 @@ class VideoProcessor:
         raw = self.consumer_stream(name)
         ext = torch.cuda.ExternalStream(raw, device=self.device)
         ext.wait_stream(torch.cuda.current_stream(self.device))
-        return raw
+        return raw, ext
 
     def get_coeffs(self):
         c = N.Coeffs()
