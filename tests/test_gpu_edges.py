@@ -1,0 +1,110 @@
+"""GPU: edge cases -- tiny and huge frames, tile-boundary sizes, ragged pitches, unaligned outputs, odd crop boxes
+at the frame border, every resize type at each."""
+import numpy as np
+import pytest
+import torch
+
+from util import synth_nv12, ulp_diff
+
+pytestmark = pytest.mark.gpu
+RT = [0, 1, 2, 3]
+
+
+def conv(vpp, oracle, y, uv, width=None, out=None, **kw):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=kw.get("dst", (0, 0))[0], height=kw.get("dst", (0, 0))[1], crop_coords=kw.get("crop", (0, 0, 0, 0)),
+                            resize_type=kw.get("rt", 0), pixel_format=kw.get("fourcc", 2), planes_pos=kw.get("planes", 0),
+                            normalization=kw.get("norm", False))
+    got = vpp.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=width, out=out)
+    torch.cuda.synchronize()
+    ref, ow, oh = oracle.convert(y, uv, crop=kw.get("crop", (0, 0, 0, 0)), dst=kw.get("dst", (0, 0)), resize_type=kw.get("rt", 0),
+                                 fourcc=kw.get("fourcc", 2), planes=kw.get("planes", 0), normalization=kw.get("norm", False), nthreads=8, width=width)
+    g = got.cpu().numpy().ravel()
+    assert g.size == ref.size
+    assert np.array_equal(g.view(np.uint8), ref.view(np.uint8)), kw
+    return got
+
+
+@pytest.mark.parametrize("rt", RT)
+@pytest.mark.parametrize("src,dst", [((2, 2), (0, 0)), ((2, 2), (4, 4)), ((4, 4), (2, 2)), ((16, 2), (4, 2)), ((2, 16), (2, 4)),
+                                     ((6, 4), (8, 6)), ((128, 16), (132, 18)), ((130, 18), (128, 16)), ((256, 32), (124, 14))])
+def test_tiny_and_tile_boundary_sizes(vpp, oracle, rt, src, dst):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] * 7 + src[1] + rt)
+    conv(vpp, oracle, y, uv, dst=dst, rt=rt, planes=0, norm=True)
+    conv(vpp, oracle, y, uv, dst=dst, rt=rt, planes=1, norm=False)
+
+
+@pytest.mark.parametrize("rt", RT)
+def test_ragged_pitches_and_sub_pitch_width(vpp, oracle, rt):
+    # pitch not a multiple of 16 / 4, width smaller than pitch, different for tests of the per-row LDS shift
+    for pitch, w in [(1083, 1080), (1000, 998), (649, 640)]:
+        h = 120
+        rng = np.random.default_rng(pitch + rt)
+        y = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+        uv = rng.integers(0, 256, (h // 2, pitch), dtype=np.uint8)
+        conv(vpp, oracle, y, uv, width=w, dst=(w // 2 + (w // 2) % 2, 90), rt=rt, planes=0, norm=True)
+        conv(vpp, oracle, y, uv, width=w, crop=(5, 3, w - 3, h - 1) if (w - 8) % 2 == 0 else (4, 2, w - 4, h - 2), dst=(320, 64), rt=rt, planes=1)
+
+
+@pytest.mark.parametrize("rt", RT)
+def test_unaligned_output_pointer_takes_scalar_path(vpp, oracle, rt):
+    y, uv = synth_nv12(640, 360, seed=77 + rt)
+    base = torch.empty(3 * 320 * 180 * 4 + 64, dtype=torch.uint8, device="cuda")
+    for off, norm in [(1, False), (4, True)]:
+        n = 3 * 320 * 180 * (4 if norm else 1)
+        view = base[off: off + n]
+        out = view.view(torch.float32 if norm else torch.uint8).view(3, 180, 320)
+        conv(vpp, oracle, y, uv, dst=(320, 180), rt=rt, planes=0, norm=norm, out=out)
+
+
+@pytest.mark.parametrize("rt", RT)
+def test_crop_boxes_touching_every_border(vpp, oracle, rt):
+    y, uv = synth_nv12(1080, 608, seed=91 + rt)
+    for crop in [(0, 0, 2, 2), (1078, 606, 1080, 608), (0, 2, 1078, 608), (2, 0, 1080, 606), (1, 1, 1079, 607), (539, 303, 541, 305)]:
+        conv(vpp, oracle, y, uv, crop=crop, planes=1)
+        conv(vpp, oracle, y, uv, crop=crop, dst=(64, 48), rt=rt, planes=0, norm=True)
+
+
+@pytest.mark.parametrize("rt", RT)
+def test_8k_frame(vpp, oracle, rt):
+    """7680x4320 (33 Mpx > 2^24): the kernels index with integers; BILINEAR/AREA-up are excluded from the comparison
+    because the reference's float start index (src/Resize.cu:6) loses precision there."""
+    y, uv = synth_nv12(7680, 4320, seed=5)
+    if rt in (0, 2):
+        conv(vpp, oracle, y, uv, dst=(1920, 1080), rt=rt, planes=1)
+    else:
+        conv(vpp, oracle, y, uv, dst=(3840, 2160) if rt == 3 else (1920, 1080), rt=3, planes=0, norm=True)
+
+
+def test_no_resize_8k_and_max_batch_split(vpp, oracle):
+    import tensor_stream as ts
+    y, uv = synth_nv12(7680, 4320, seed=6)
+    conv(vpp, oracle, y, uv, planes=0, norm=True)
+    # 130 frames -> 3 launches (64 + 64 + 2), frames at unrelated addresses
+    frames = [synth_nv12(64, 36, seed=i) for i in range(130)]
+    ys = [torch.from_numpy(f[0]).cuda() for f in frames]
+    uvs = [torch.from_numpy(f[1]).cuda() for f in frames]
+    fp = ts.FrameParameters(width=96, height=54, resize_type=1, pixel_format=1, planes_pos=1, normalization=False)
+    out = vpp.convert_batch(ys, uvs, fp)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    for i in (0, 63, 64, 127, 128, 129):
+        ref, _, _ = oracle.convert(frames[i][0], frames[i][1], dst=(96, 54), resize_type=1, fourcc=1, planes=1)
+        assert np.array_equal(o[i].ravel(), ref)
+
+
+def test_empty_batch_and_argument_errors(vpp):
+    import ctypes
+    import tensor_stream as ts
+    from tensor_stream import _native as N
+    L = N.lib()
+    fp = ts.FrameParameters().parameters
+    assert L.tsvpp_convert_batch(vpp._ctx, 0, None, ctypes.byref(fp), None, None) == -3      # null arrays
+    frames = (N.NV12 * 1)(N.NV12(0, 0, 0, 0, 64, 36))
+    outs = (ctypes.c_void_p * 1)(0)
+    assert L.tsvpp_convert_batch(vpp._ctx, 0, frames, ctypes.byref(fp), outs, None) == 0     # n = 0: nothing to do
+    assert L.tsvpp_convert_batch(vpp._ctx, 1, frames, ctypes.byref(fp), outs, None) == -3    # null planes
+    y = torch.zeros((36, 64), dtype=torch.uint8, device="cuda")
+    bad = (N.NV12 * 1)(N.NV12(y.data_ptr(), y.data_ptr(), 32, 32, 64, 36))                   # pitch < width
+    outs = (ctypes.c_void_p * 1)(y.data_ptr())
+    assert L.tsvpp_convert_batch(vpp._ctx, 1, bad, ctypes.byref(fp), outs, None) == -3
