@@ -148,6 +148,7 @@ struct tsvpp_ctx {
     int nt_stores = 0, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
+    int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
     // NV12 intermediates for the two-pass formats, one grow-only buffer per stream
     std::map<void *, std::pair<uint8_t *, size_t>> scratch;
@@ -293,6 +294,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = (e[0] == '1');
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
@@ -422,6 +424,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.shape_ty = ctx->shape_ty;
     d.ablate = ctx->ablate;
     d.persist = ctx->persist;
+    d.dma = ctx->dma;
     d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;

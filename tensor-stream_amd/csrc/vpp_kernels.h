@@ -60,6 +60,7 @@ struct LaunchDesc {
     int nt_stores;    // 1 = non-temporal output stores
     int tile_order;   // 0 = tile row per XCD (default), 1 = raster, 2 = XCD-contiguous runs
     int shape_tx, shape_ty; // != 0: force the workgroup shape
+    int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic

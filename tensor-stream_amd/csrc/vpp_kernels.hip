@@ -632,6 +632,28 @@ __device__ __forceinline__ void stage_planes(const LaunchDesc &d, uint8_t *lds_y
     }
 }
 
+// LDS-DMA variant (global_load_lds_dwordx4): the chunks go straight from HBM into LDS, no VGPR
+// round trip and no ds_write.  Lane l of a wave instruction lands in LDS slot (wave base + 16 l),
+// so it needs the row pitch to be a power-of-two number of chunks (16 << slot): then the slot of
+// (row r, chunk ch) IS 16 * thread-linear index.  Idle lanes (ch >= cpr, rows past the footprint)
+// fetch a clamped valid chunk into their padding slot.  Rows must be allocated up to a multiple
+// of the rows per round.  The caller waits (vmcnt(0)) and barriers.
+__device__ __forceinline__ void stage_plane_dma(uint8_t *lds, const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span,
+                                                int slot_shift, int nthreads) {
+    const int ch = threadIdx.x & ((1 << slot_shift) - 1);
+    const int r0 = threadIdx.x >> slot_shift;
+    const int rstep = nthreads >> slot_shift;
+    const int wave_row0 = (int)((threadIdx.x & ~63u) >> slot_shift); // first row this wave serves in round 0
+    for (int base = 0; base + wave_row0 < nrows; base += rstep) {     // wave-uniform trip count
+        const int rc = min(base + r0, nrows - 1);
+        const int mis = (lp.m0 + rc * lp.pm) & 15;
+        const int chmax = (mis + span - 1) >> 4;
+        const uint8_t *src = a0 + (size_t)rc * (size_t)pitch - mis + 16 * min(ch, chmax);
+        uint8_t *dst = lds + ((base << slot_shift) + (int)(threadIdx.x & ~63u)) * 16; // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+}
+
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
 // ----------------------------------------------------------------------------------------------
@@ -651,8 +673,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const Lau
     const uint8_t *ay, *auv;
     s.py_ = describe_plane(lds_raw, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     s.puv_ = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    stage_planes<4, 2>(d, lds_raw, ay, s.py_, min(f.yhi - f.ylo + 1, d.lds_rows_y), min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, s.puv_,
-                       min(f.cyhi - f.cylo + 1, d.lds_rows_uv), min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
+    if (d.dma) {
+        stage_plane_dma(lds_raw, ay, s.py_, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
+        stage_plane_dma(lds_uv, auv, s.puv_, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        stage_planes<4, 2>(d, lds_raw, ay, s.py_, ny, spy, lds_uv, auv, s.puv_, nuv, spuv, nthreads);
+    }
     __syncthreads();
 
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
@@ -796,8 +825,13 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 #ifdef TSVPP_ABLATION
     if (!(d.ablate & 2))
 #endif
+    if (d.dma) {
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_slot_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_slot_uv, nthreads);
+    } else {
         stage_planes<2, 1>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
                            min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    }
 
     // coordinate tables (one entry per lane)
     const int ntab = tw + (tw >> 1) + th + (th >> 1);
@@ -823,6 +857,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
             cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15), w, 0 };
         }
     }
+    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA chunks have landed
     __syncthreads();
     // replicate the last column / chroma pair one step past the plane (tiles on the right edge only)
     const bool edge_y = (f.xhi == d.src_w - 1), edge_uv = (f.cxhi == cw - 1);
@@ -1005,16 +1040,18 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     // small workgroups (large footprints) must keep many chunks per lane in flight, or the staging
-    // is latency-bound: 64 threads -> 16 + 8 chunks per lane, 256 threads -> 4 + 2
-    if (nthreads <= 64)
-        stage_planes<16, 8>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
-                            min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+    // is latency-bound: LDS-DMA issues them all without holding registers; the register path keeps
+    // 16 + 8 chunks per lane for 64 threads, 4 + 2 for 256
+    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
+    if (d.dma) {
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+    } else if (nthreads <= 64)
+        stage_planes<16, 8>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     else if (nthreads <= 128)
-        stage_planes<8, 4>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
-                           min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+        stage_planes<8, 4>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     else
-        stage_planes<4, 2>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
-                           min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
+        stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     const int ntab = tw + (tw >> 1) + th + (th >> 1) + d.lds_rows_y + d.lds_rows_uv;
     for (int e = threadIdx.x; e < ntab; e += nthreads) {
         int k = e;
@@ -1049,6 +1086,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         if (k < d.lds_rows_y) rby[k] = k * py.lp + ((py.m0 + k * py.pm) & 15);
         else { k -= d.lds_rows_y; rbuv[k] = k * puv.lp + ((puv.m0 + k * puv.pm) & 15); }
     }
+    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
@@ -1357,38 +1395,53 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.point_kind = PK_NONE;
     }
     if (!staged && mode != M_NONE && vec && !d.force_gather) {
+        const int want_dma = d.dma;
         for (auto &sh : shapes) {
-            if (sh[0] == 0) break;
+            if (sh[0] == 0 || staged) break;
             const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
             const int rows_y = span_bound(mode, sh[1] * PXH, d.yr, d.ry);
             const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
             const int rows_uv = span_bound(mode, sh[1] * PXH / 2, d.yr, d.ry);
-            const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
             const int nthreads = sh[0] * sh[1];
-            if (cpr_y > nthreads || cpr_uv > nthreads) continue;
-            size_t need = (size_t)16 * ((size_t)rows_y * cpr_y + (size_t)rows_uv * cpr_uv);
-            if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
-                need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
-                        (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_y + rows_uv) + 32;
-            if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
-                need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
-            if (need <= kLdsBudget) {
+            // per shape: the LDS-DMA layout first (power-of-two chunks per row, rows padded to whole
+            // rounds), then the compact register-staged layout
+            for (int layout = want_dma ? 1 : 0; layout >= 0 && !staged; layout--) {
+                int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
+                if (cpr_y > nthreads || cpr_uv > nthreads) break;
+                int rows_alloc_y = rows_y, rows_alloc_uv = rows_uv;
+                const bool dma = layout == 1 && nthreads >= 64;
+                if (layout == 1 && !dma) continue;
+                if (dma) {
+                    cpr_y = 1 << slot_shift_for(cpr_y);
+                    cpr_uv = 1 << slot_shift_for(cpr_uv);
+                    const int rs_y = nthreads / cpr_y, rs_uv = nthreads / cpr_uv;
+                    rows_alloc_y = (rows_y + rs_y - 1) / rs_y * rs_y;
+                    rows_alloc_uv = (rows_uv + rs_uv - 1) / rs_uv * rs_uv;
+                }
+                size_t need = (size_t)16 * ((size_t)rows_alloc_y * cpr_y + (size_t)rows_alloc_uv * cpr_uv);
+                if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
+                    need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
+                            (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
+                if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
+                    need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
+                if (need > kLdsBudget) continue;
                 staged = true;
                 lds_bytes = need;
                 d.tx = sh[0];
                 d.ty = sh[1];
                 d.lds_span_y = span_y;
-                d.lds_rows_y = rows_y;
+                d.lds_rows_y = rows_alloc_y;
                 d.lds_cpr_y = cpr_y;
                 d.lds_slot_y = slot_shift_for(cpr_y);
                 d.lds_span_uv = span_uv;
-                d.lds_rows_uv = rows_uv;
+                d.lds_rows_uv = rows_alloc_uv;
                 d.lds_cpr_uv = cpr_uv;
                 d.lds_slot_uv = slot_shift_for(cpr_uv);
-                break;
+                d.dma = dma ? 1 : 0;
             }
         }
     }
+    if (!staged) d.dma = 0;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     d.tx_shift = slot_shift_for(d.tx);
     const int tile_w = d.tx * PXW, tile_h = d.ty * PXH;
