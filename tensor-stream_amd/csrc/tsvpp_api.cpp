@@ -148,6 +148,7 @@ struct tsvpp_ctx {
     int nt_stores = 0, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
+    float area_direct_min = 2.0f;   // TSVPP_AREA_DIRECT_MIN
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
     // NV12 intermediates for the two-pass formats, one grow-only buffer per stream
@@ -295,6 +296,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
@@ -425,6 +427,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.ablate = ctx->ablate;
     d.persist = ctx->persist;
     d.dma = ctx->dma;
+    d.area_direct_min = ctx->area_direct_min;
     d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;

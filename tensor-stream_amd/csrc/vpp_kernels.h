@@ -60,6 +60,8 @@ struct LaunchDesc {
     int nt_stores;    // 1 = non-temporal output stores
     int tile_order;   // 0 = tile row per XCD (default), 1 = raster, 2 = XCD-contiguous runs
     int shape_tx, shape_ty; // != 0: force the workgroup shape
+    int area_direct;        // (launch_fused) dyadic AREA straight from global memory
+    float area_direct_min;  // use it when both ratios are >= this (0 = never)
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)

@@ -884,16 +884,12 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 }
 
 // ----------------------------------------------------------------------------------------------
-// Persistent variant of the 2x2-tap kernel.  The one-tile-per-workgroup kernel above exposes the
-// full (loaded-HBM) read latency once per workgroup lifetime and has nothing in flight for that
-// workgroup while it computes.  Here a fixed grid of resident workgroups walks the tile list
-// (tile = block + k * grid: neighbouring workgroups still write neighbouring tiles) and keeps the
-// NEXT tile's 16-byte chunks in flight -- in registers -- while the current tile is blended,
-// colour-converted and stored; one LDS buffer, two barriers per tile.
-struct StageRegs {
-    uint4 y[2], uv[1];
-    bool oky[2], okuv[1];
-};
+// Persistent variant of the 2x2-tap kernel (opt-in, TSVPP_PERSIST=k workgroups per CU).  A fixed
+// grid of resident workgroups walks the tile list (tile = block + i * grid: neighbouring
+// workgroups still write neighbouring tiles).  LDS holds TWO tile sets; while set `cur` is blended,
+// colour-converted and stored, the NEXT tile's chunks stream into the other set by LDS-DMA -- no
+// registers held across the compute phase -- and its coordinate tables are built.  One barrier per
+// tile (two on right-edge tiles).
 struct TileCtx {
     TileId id;
     Footprint f;
@@ -917,6 +913,7 @@ __device__ __forceinline__ void tile_ctx(const LaunchDesc &d, const FrameTable &
     c.span_y = min(c.f.xhi - c.f.xlo + 1, d.lds_span_y);
     c.span_uv = min(2 * (c.f.cxhi - c.f.cxlo + 1), d.lds_span_uv);
 }
+
 template <bool AREAUP, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
@@ -925,31 +922,24 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
     const int tw = d.tx * PXW, th = d.ty * PXH;
     const int total = d.tiles_x * d.tiles_y * d.n_frames;
     const int cw = d.src_w >> 1, chh = d.src_h >> 1;
-    uint8_t *lds_y = lds_raw;
-    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
-    XEntry *xtab = (XEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
-    XEntry *cxtab = xtab + tw;
-    YEntry *ytab = (YEntry *)(cxtab + (tw >> 1));
-    YEntry *cytab = ytab + th;
+    const int y_bytes = d.lds_rows_y * d.lds_cpr_y * 16, uv_bytes = d.lds_rows_uv * d.lds_cpr_uv * 16;
+    const int tab_bytes = (tw + (tw >> 1)) * (int)sizeof(XEntry) + (th + (th >> 1)) * (int)sizeof(YEntry);
+    const int set_bytes = y_bytes + uv_bytes + tab_bytes;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
 
     int tile = blockIdx.x;
     if (tile >= total) return;
-    const StageLane lny = stage_lane(d.lds_slot_y, nthreads), lnuv = stage_lane(d.lds_slot_uv, nthreads);
-    StageRegs R;
-    {
-        TileCtx c0;
-        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, c0);
-        stage_issue<2>(c0.ay, c0.py, d.pitch_y, c0.ny, c0.span_y, d.lds_cpr_y, lny, 0, R.y, R.oky);
-        stage_issue<1>(c0.auv, c0.puv, d.pitch_uv, c0.nuv, c0.span_uv, d.lds_cpr_uv, lnuv, 0, R.uv, R.okuv);
-    }
-    for (;;) {
-        TileCtx cur; // uniform: recomputed instead of carried across the loop
-        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, cur);
-        stage_commit<2>(lds_y, cur.py, lny, 0, R.y, R.oky); // waits for the chunks, writes them to LDS
-        stage_commit<1>(lds_uv, cur.puv, lnuv, 0, R.uv, R.okuv);
-        const Footprint &f = cur.f;
-        const LdsPlane &py = cur.py, &puv = cur.puv;
+
+    // stream a tile into LDS set `set` (DMA, asynchronous) and build its coordinate tables
+    auto issue = [&](int tl, int set) {
+        uint8_t *ly_ = lds_raw + set * set_bytes, *luv_ = ly_ + y_bytes;
+        XEntry *xtab = (XEntry *)(luv_ + uv_bytes), *cxtab = xtab + tw;
+        YEntry *ytab = (YEntry *)(cxtab + (tw >> 1)), *cytab = ytab + th;
+        TileCtx c;
+        tile_ctx<MODE>(d, t, tl, ly_, luv_, c);
+        stage_plane_dma(ly_, c.ay, c.py, d.pitch_y, c.ny, c.span_y, d.lds_slot_y, nthreads);
+        stage_plane_dma(luv_, c.auv, c.puv, d.pitch_uv, c.nuv, c.span_uv, d.lds_slot_uv, nthreads);
+        const Footprint &f = c.f;
         const int ntab = tw + (tw >> 1) + th + (th >> 1);
         for (int e = threadIdx.x; e < ntab; e += nthreads) {
             int p;
@@ -965,33 +955,39 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
                 const int k = e - tw - (tw >> 1);
                 axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
                 const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo;
-                ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15), w, 0 };
+                ytab[k] = YEntry{ r0 * c.py.lp + ((c.py.m0 + r0 * c.py.pm) & 15), r1 * c.py.lp + ((c.py.m0 + r1 * c.py.pm) & 15), w, 0 };
             } else {
                 const int k = e - tw - (tw >> 1) - th;
                 axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
                 const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
-                cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15), w, 0 };
+                cytab[k] = YEntry{ r0 * c.puv.lp + ((c.puv.m0 + r0 * c.puv.pm) & 15), r1 * c.puv.lp + ((c.puv.m0 + r1 * c.puv.pm) & 15), w, 0 };
             }
         }
-        __syncthreads();
-        // next tile's chunks go in flight now and land while this tile is computed and stored
+    };
+
+    issue(tile, 0);
+    int cur = 0;
+    for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA chunks of set `cur` have landed
+        __syncthreads();                                  // ... everybody's, and the tables are visible
         const int next = tile + (int)gridDim.x;
-        if (next < total) {
-            TileCtx nxt;
-            tile_ctx<MODE>(d, t, next, lds_y, lds_uv, nxt);
-            stage_issue<2>(nxt.ay, nxt.py, d.pitch_y, nxt.ny, nxt.span_y, d.lds_cpr_y, lny, 0, R.y, R.oky);
-            stage_issue<1>(nxt.auv, nxt.puv, d.pitch_uv, nxt.nuv, nxt.span_uv, d.lds_cpr_uv, lnuv, 0, R.uv, R.okuv);
-        }
+        if (next < total) issue(next, cur ^ 1);           // in flight during everything below
+        uint8_t *lds_y = lds_raw + cur * set_bytes, *lds_uv = lds_y + y_bytes;
+        XEntry *xtab = (XEntry *)(lds_uv + uv_bytes), *cxtab = xtab + tw;
+        YEntry *ytab = (YEntry *)(cxtab + (tw >> 1)), *cytab = ytab + th;
+        TileCtx c; // uniform; recomputed rather than carried across the loop
+        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, c);
+        const Footprint &f = c.f;
         const bool edge_y = (f.xhi == d.src_w - 1), edge_uv = (f.cxhi == cw - 1);
         if (edge_y || edge_uv) {
             if (edge_y)
-                for (int r = threadIdx.x; r < cur.ny; r += nthreads) {
-                    uint8_t *q = lds_y + r * py.lp + ((py.m0 + r * py.pm) & 15) + (d.src_w - f.xlo);
+                for (int r = threadIdx.x; r < c.ny; r += nthreads) {
+                    uint8_t *q = lds_y + r * c.py.lp + ((c.py.m0 + r * c.py.pm) & 15) + (d.src_w - f.xlo);
                     q[0] = q[-1];
                 }
             if (edge_uv)
-                for (int r = threadIdx.x; r < cur.nuv; r += nthreads) {
-                    uint8_t *q = lds_uv + r * puv.lp + ((puv.m0 + r * puv.pm) & 15) + 2 * (cw - f.cxlo);
+                for (int r = threadIdx.x; r < c.nuv; r += nthreads) {
+                    uint8_t *q = lds_uv + r * c.puv.lp + ((c.puv.m0 + r * c.puv.pm) & 15) + 2 * (cw - f.cxlo);
                     q[0] = q[-2];
                     q[1] = q[-1];
                 }
@@ -999,10 +995,10 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
         }
         const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
         if (j0 < d.dst_w && i0 < d.dst_h)
-            bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[cur.id.frame], i0, j0);
+            bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
         if (next >= total) break;
-        __syncthreads(); // everyone is done reading this tile's LDS before the next one overwrites it
         tile = next;
+        cur ^= 1;
     }
 }
 
@@ -1147,6 +1143,135 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
             }
 #pragma unroll
             for (int c = 0; c < PXW; c++) Yf[r][c] = __builtin_truncf((float)sum[c] / (float)(xe[c].sum * ye.sum));
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Dyadic AREA for LARGE ratios (>= 2 in both axes), straight from global memory.  A 6x6 box tile
+// needs 36 source bytes per output pixel: staged in LDS that is ~30 KiB per 64 threads, i.e. five
+// waves per CU, and the kernel becomes latency-bound.  Here every thread reads the 2-3 aligned
+// dwords that cover one box row itself (adjacent lanes read adjacent, slightly overlapping spans,
+// so the wave's requests still coalesce into full lines) and reduces them with
+// v_alignbyte_b32 + v_dot4_u32_u8 as above: no LDS, no barrier, occupancy limited by VGPRs only.
+// A dword that the box does not reach is re-pointed at dword 0, so nothing is read beyond the
+// last needed byte's dword (no over-read past the end of the plane).
+typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+// N + 1 aligned dwords starting at the dword that holds byte `a`.  WIDE: one vector load (the row is
+// not the plane's last one, so the few bytes past the box still belong to the plane); otherwise
+// dword by dword, and a dword the box does not reach is re-pointed at dword 0 -- nothing is read
+// beyond the dword of the last needed byte.
+// `plane` is the frame's (wave-uniform) plane pointer and `off` a 32-bit byte offset: the loads use
+// the SGPR-base + VGPR-offset addressing mode; `pm` = plane pointer & 3 (uniform).
+template <int N, bool WIDE>
+__device__ __forceinline__ void load_span(const uint8_t *plane, uint32_t pm, uint32_t off, int nbytes, uint32_t (&dw)[N + 1], uint32_t &sh) {
+    sh = (pm + off) & 3u;
+    const uint32_t *p = (const uint32_t *)(plane + (off - sh)); // aligned dword of the first byte
+    if constexpr (WIDE) {
+        if constexpr (N == 1) {
+            const u32x2a4 v = *(const u32x2a4 *)p;
+            dw[0] = v.x; dw[1] = v.y;
+        } else if constexpr (N == 2) {
+            const u32x3a4 v = *(const u32x3a4 *)p;
+            dw[0] = v.x; dw[1] = v.y; dw[2] = v.z;
+        } else {
+            static_assert(N == 4, "span width");
+            const u32x4a4 v = *(const u32x4a4 *)p;
+            dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+            dw[4] = p[4];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k <= N; k++) dw[k] = p[(4 * k < (int)sh + nbytes) ? k : 0];
+    }
+}
+
+template <int NW, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const uint8_t *Y = t.y[id.frame], *UV = t.uv[id.frame];
+    const uint32_t ym = (uint32_t)((uintptr_t)Y & 3), uvm = (uint32_t)((uintptr_t)UV & 3);
+    const int ci = i0 >> 1, cj0 = j0 >> 1;
+
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    { // chroma: U on even bytes, V on odd bytes of the same dwords
+        const AreaQRow qy = d.qy[ci % d.ny];
+        const int y0 = (int)(d.yr * (float)ci);
+        AreaQRow qx[2];
+        int xo[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            qx[c] = d.qx[(cj0 + c) % d.nx];
+            xo[c] = 2 * (int)(d.xr * (float)(cj0 + c));
+        }
+        uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
+        for (int a = 0; a < d.ry; a++) {
+            const uint32_t wy = (qy.w[a >> 2] >> (8 * (a & 3))) & 255u;
+            const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_uv;
+            const bool wide = (y0 + a) < (d.src_h >> 1) - 1; // not the plane's last row
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                uint32_t dw[2 * NW + 1], sh;
+                if (wide) load_span<2 * NW, true>(UV, uvm, row + (uint32_t)xo[c], 2 * d.rx, dw, sh);
+                else load_span<2 * NW, false>(UV, uvm, row + (uint32_t)xo[c], 2 * d.rx, dw, sh);
+                uint32_t ru = 0, rv = 0;
+#pragma unroll
+                for (int k = 0; k < 2 * NW; k++) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], sh);
+                    ru = __builtin_amdgcn_udot4(v, qx[c].wu[k], ru, false);
+                    rv = __builtin_amdgcn_udot4(v, qx[c].wu[k] << 8, rv, false);
+                }
+                su[c] += wy * ru;
+                sv[c] += wy * rv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float div = (float)(qx[c].sum * qy.sum);
+            Uf[c] = __builtin_truncf((float)su[c] / div);
+            Vf[c] = __builtin_truncf((float)sv[c] / div);
+        }
+    }
+    {
+        int xo[PXW], xs[PXW];
+        uint32_t w0[PXW], w1[PXW];
+#pragma unroll
+        for (int c = 0; c < PXW; c++) {
+            const AreaQRow q = d.qx[(j0 + c) % d.nx];
+            xo[c] = (int)(d.xr * (float)(j0 + c));
+            xs[c] = q.sum;
+            w0[c] = q.w[0];
+            w1[c] = q.w[1];
+        }
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const AreaQRow qy = d.qy[(i0 + r) % d.ny];
+            const int y0 = (int)(d.yr * (float)(i0 + r));
+            uint32_t sum[PXW] = { 0, 0, 0, 0 };
+            for (int a = 0; a < d.ry; a++) {
+                const uint32_t wy = (qy.w[a >> 2] >> (8 * (a & 3))) & 255u;
+                const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_y;
+                const bool wide = (y0 + a) < d.src_h - 1; // not the plane's last row
+#pragma unroll
+                for (int c = 0; c < PXW; c++) {
+                    uint32_t dw[NW + 1], sh;
+                    if (wide) load_span<NW, true>(Y, ym, row + (uint32_t)xo[c], d.rx, dw, sh);
+                    else load_span<NW, false>(Y, ym, row + (uint32_t)xo[c], d.rx, dw, sh);
+                    uint32_t rs = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(dw[1], dw[0], sh), w0[c], 0u, false);
+                    if constexpr (NW == 2) rs = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(dw[2], dw[1], sh), w1[c], rs, false);
+                    sum[c] += wy * rs;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < PXW; c++) Yf[r][c] = __builtin_truncf((float)sum[c] / (float)(xs[c] * qy.sum));
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
@@ -1300,14 +1425,12 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
         return launch_point<OUT>(d, t, lds_bytes, stream);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
-            // persistent variant: needs <= 2 luma and <= 1 chroma staging rounds per thread
-            const int nthreads = d.tx * d.ty;
-            const bool fits = (2 * (nthreads >> d.lds_slot_y) >= d.lds_rows_y) && ((nthreads >> d.lds_slot_uv) >= d.lds_rows_uv);
-            if (d.persist > 0 && fits) {
+            // persistent variant: two LDS tile sets filled by LDS-DMA
+            if (d.persist > 0 && d.dma && 2 * lds_bytes <= 64 * 1024) {
                 const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
                 const long resident = (long)d.num_cus * d.persist;
                 dim3 pgrid((unsigned)(total < resident ? total : resident));
-                hipLaunchKernelGGL((vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, lds_bytes, stream, d, t);
+                hipLaunchKernelGGL((vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, 2 * lds_bytes, stream, d, t);
                 return hipGetLastError();
             }
             hipLaunchKernelGGL((vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes, stream, d, t);
@@ -1315,6 +1438,11 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
         }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
+            if (vec && d.area_direct && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
+                if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_direct_kernel<1, OUT>), grid, block, 0, stream, d, t);
+                else hipLaunchKernelGGL((vpp_area_direct_kernel<2, OUT>), grid, block, 0, stream, d, t);
+                return hipGetLastError();
+            }
             if (staged && d.qx && d.qy) {
                 if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, OUT>), grid, block, lds_bytes, stream, d, t);
                 else hipLaunchKernelGGL((vpp_area_dyadic_kernel<2, OUT>), grid, block, lds_bytes, stream, d, t);
@@ -1366,6 +1494,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     size_t lds_bytes = 0;
     d.tx = shapes[0][0];
     d.ty = shapes[0][1];
+    if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
+        d.yr >= d.area_direct_min)
+        d.area_direct = 1;
+    else
+        d.area_direct = 0;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
     if (point && vec && !d.force_gather) {
@@ -1394,7 +1527,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     } else {
         d.point_kind = PK_NONE;
     }
-    if (!staged && mode != M_NONE && vec && !d.force_gather) {
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
