@@ -107,6 +107,57 @@ __device__ __forceinline__ int cubic4(const double c[4], int p0, int p1, int p2,
     s = s + a3;
     return clamp255((int)round(s));
 }
+// Mixed-precision form of cubic4.  The reference's value is round(s64) of a 4-term fp64 sum that is
+// at most a few hundred in magnitude; an fp32 evaluation s32 of the same sum differs from it by far
+// less than CUBIC_DELTA (coefficient rounding 255*4*6e-8, products and sums < 2e-4 in total), so
+// wherever s32 is further than CUBIC_DELTA from a half-integer round(s32) == round(s64) and the
+// fp64 arithmetic (half rate, plus the coefficient polynomials) is skipped.  The few lanes that are
+// close to a tie recompute exactly as the reference does.  `w` is the weight as a float: it IS
+// exact (fraction of a float coordinate).
+constexpr float CUBIC_DELTA = 5e-4f;
+__device__ __forceinline__ void cubic_coeffs_f(float w, float c[4]) {
+    const float a = -0.75f;
+    const float w2 = w * w, w3 = w2 * w;
+    c[0] = (a * w - (2 * a) * w2) + a * w3;
+    c[1] = (1 - (a + 3) * w2) + (a + 2) * w3;
+    c[2] = ((-a) * w + (2 * a + 3) * w2) - (a + 2) * w3;
+    c[3] = a * w2 - a * w3;
+}
+__device__ __forceinline__ int cubic4_mixed(float w, const float cf[4], int p0, int p1, int p2, int p3) {
+    const float s = ((cf[0] * (float)p0 + cf[1] * (float)p1) + cf[2] * (float)p2) + cf[3] * (float)p3;
+    const float fl = floorf(s);
+    if (fabsf((s - fl) - 0.5f) < CUBIC_DELTA) { // within reach of a tie: the reference's fp64 arithmetic decides
+        double c[4];
+        cubic_coeffs((double)w, c);
+        return cubic4(c, p0, p1, p2, p3);
+    }
+    return clamp255((int)fl + ((s - fl) > 0.5f ? 1 : 0)); // round to nearest; negative sums clamp to 0 either way
+}
+
+// Two 4-tap sums at once on float pairs (packed VALU).  Rounding by the 1.5 * 2^23 trick (nearest
+// even -- it differs from the reference's half-away rule only AT a tie, and anything within
+// CUBIC_DELTA of a tie is recomputed exactly); results stay integer-valued floats, clamped.
+__device__ __forceinline__ f2 cubic4_pair(float w0, float w1, const float c0[4], const float c1[4], const f2 p[4], const int q0[4], const int q1[4]) {
+    f2 s = ((f2){ c0[0], c1[0] } * p[0] + (f2){ c0[1], c1[1] } * p[1]) + (f2){ c0[2], c1[2] } * p[2];
+    s = s + (f2){ c0[3], c1[3] } * p[3];
+    const f2 magic = { 12582912.0f, 12582912.0f };
+    f2 r = (s + magic) - magic;
+    const f2 dd = s - r;
+    r.x = __builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f);
+    r.y = __builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);
+    if (fabsf(dd.x) > 0.5f - CUBIC_DELTA) {
+        double c[4];
+        cubic_coeffs((double)w0, c);
+        r.x = (float)cubic4(c, q0[0], q0[1], q0[2], q0[3]);
+    }
+    if (fabsf(dd.y) > 0.5f - CUBIC_DELTA) {
+        double c[4];
+        cubic_coeffs((double)w1, c);
+        r.y = (float)cubic4(c, q1[0], q1[1], q1[2], q1[3]);
+    }
+    return r;
+}
+
 // Tap offsets with the reference's edge rule (src/Resize.cu:32-43): the +1 AND +2 taps collapse
 // onto the centre when either would leave the plane; the -1 tap collapses at the low edge.
 __device__ __forceinline__ void bicubic_offsets(int p, int step, int limit, int &lo, int &hi) {
@@ -150,15 +201,16 @@ __device__ __forceinline__ int sample_luma(const S &s, const LaunchDesc &d, int 
         int xl, xh, yl, yh;
         bicubic_offsets(x, 1, s.w, xl, xh);
         bicubic_offsets(y, 1, s.h, yl, yh);
-        double cx[4], cy[4];
-        cubic_coeffs(wx, cx);
-        cubic_coeffs(wy, cy);
+        const float wxf = (float)wx, wyf = (float)wy; // exact
+        float cx[4], cy[4];
+        cubic_coeffs_f(wxf, cx);
+        cubic_coeffs_f(wyf, cy);
         const int rows[4] = { y - yl, y, y + yh, y + 2 * yh };
         int b[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            b[r] = cubic4(cx, s.Y(rows[r], x - xl), s.Y(rows[r], x), s.Y(rows[r], x + xh), s.Y(rows[r], x + 2 * xh));
-        return cubic4(cy, b[0], b[1], b[2], b[3]);
+            b[r] = cubic4_mixed(wxf, cx, s.Y(rows[r], x - xl), s.Y(rows[r], x), s.Y(rows[r], x + xh), s.Y(rows[r], x + 2 * xh));
+        return cubic4_mixed(wyf, cy, b[0], b[1], b[2], b[3]);
     } else { // M_AREA_DOWN, src/Resize.cu:160-178, 186-201
         int y = (int)(d.yr * (float)i), x = (int)(d.xr * (float)j);
         const float *px = d.patx + (j % d.nx) * d.rx;
@@ -211,9 +263,10 @@ __device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, i
         bicubic_axis(ci, d.yr, s.h, y, wy);
         int yl, yh;
         bicubic_offsets(y, 1, ch, yl, yh);
-        double cx[4], cy[4];
-        cubic_coeffs(wx, cx);
-        cubic_coeffs(wy, cy);
+        const float wxf = (float)wx, wyf = (float)wy; // exact
+        float cx[4], cy[4];
+        cubic_coeffs_f(wxf, cx);
+        cubic_coeffs_f(wyf, cy);
         const int rows[4] = { y - yl, y, y + yh, y + 2 * yh };
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
@@ -222,8 +275,8 @@ __device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, i
             int b[4];
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                b[r] = cubic4(cx, s.UV(rows[r], xc - xl), s.UV(rows[r], xc), s.UV(rows[r], xc + xh), s.UV(rows[r], xc + 2 * xh));
-            int v = cubic4(cy, b[0], b[1], b[2], b[3]);
+                b[r] = cubic4_mixed(wxf, cx, s.UV(rows[r], xc - xl), s.UV(rows[r], xc), s.UV(rows[r], xc + xh), s.UV(rows[r], xc + 2 * xh));
+            int v = cubic4_mixed(wyf, cy, b[0], b[1], b[2], b[3]);
             if (comp == 0) U = v; else V = v;
         }
     } else { // M_AREA_DOWN, src/Resize.cu:204-210: same x, y and the SAME weight rows, stride 2
@@ -884,6 +937,167 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 }
 
 // ----------------------------------------------------------------------------------------------
+// BICUBIC kernel.  Same skeleton as the 2x2-tap kernel: footprint staged by LDS-DMA, per-workgroup
+// tables -- here each output column / row gets its four tap offsets (the reference's edge rule,
+// src/Resize.cu:32-43, is baked into the offsets: no clamping at tap time) and its four Keys
+// coefficients, computed once per tile instead of once per thread and pixel.  A tap is one LDS
+// byte read at rowbase + coloffset; the 4-tap sums run in fp32 with the exact fp64 fallback of
+// cubic4_mixed near ties.
+struct BXEntry { int off[4]; float c[4]; };  // LDS byte offsets of the 4 horizontal taps, coefficients
+struct BYEntry { int base[4]; float c[4]; }; // LDS row bases of the 4 vertical taps, coefficients
+
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const Footprint f = tile_footprint<M_BICUBIC>(d, id);
+    const int chh = d.src_h >> 1;
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    BXEntry *xtab = (BXEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    BXEntry *cxtab = xtab + tw;
+    BYEntry *ytab = (BYEntry *)(cxtab + (tw >> 1));
+    BYEntry *cytab = ytab + th;
+    float *wxt = (float *)(cytab + (th >> 1)); // the weights themselves, for the exact fallback
+    float *cwxt = wxt + tw, *wyt = cwxt + (tw >> 1), *cwyt = wyt + th;
+
+    const uint8_t *ay, *auv;
+    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
+    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
+    if (d.dma) {
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+    } else {
+        stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
+    }
+    const int ntab = tw + (tw >> 1) + th + (th >> 1);
+    for (int e = threadIdx.x; e < ntab; e += nthreads) {
+        int p, lo, hi;
+        double w;
+        float c[4];
+        if (e < tw + (tw >> 1)) { // columns: luma (step 1) then chroma pairs (step 2 bytes, U; V = U + 1)
+            const bool chroma = e >= tw;
+            const int k = chroma ? e - tw : e;
+            bicubic_axis((chroma ? (f.j_first >> 1) : f.j_first) + k, d.xr, d.src_w, p, w);
+            cubic_coeffs_f((float)w, c);
+            BXEntry en;
+            if (!chroma) {
+                bicubic_offsets(p, 1, d.src_w, lo, hi);
+                const int o = p - f.xlo;
+                en = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
+                xtab[k] = en;
+                wxt[k] = (float)w;
+            } else {
+                bicubic_offsets(2 * p, 2, d.src_w, lo, hi);
+                const int o = 2 * (p - f.cxlo);
+                en = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
+                cxtab[k] = en;
+                cwxt[k] = (float)w;
+            }
+        } else { // rows
+            const int q = e - tw - (tw >> 1);
+            const bool chroma = q >= th;
+            const int k = chroma ? q - th : q;
+            bicubic_axis((chroma ? (f.i_first >> 1) : f.i_first) + k, d.yr, d.src_h, p, w);
+            cubic_coeffs_f((float)w, c);
+            bicubic_offsets(p, 1, chroma ? chh : d.src_h, lo, hi);
+            const LdsPlane &pl = chroma ? puv : py;
+            const int r0 = p - (chroma ? f.cylo : f.ylo);
+            const int rr[4] = { r0 - lo, r0, r0 + hi, r0 + 2 * hi };
+            BYEntry en;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                en.base[a] = rr[a] * pl.lp + ((pl.m0 + rr[a] * pl.pm) & 15);
+                en.c[a] = c[a];
+            }
+            if (!chroma) { ytab[k] = en; wyt[k] = (float)w; }
+            else { cytab[k] = en; cwyt[k] = (float)w; }
+        }
+    }
+    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    { // chroma: (U, V) evaluated as a pair -- same weights, tap addresses one byte apart
+        const BYEntry ye = cytab[ly];
+        const float wy = cwyt[ly];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const BXEntry xe = cxtab[lx * 2 + c];
+            const float wx = cwxt[lx * 2 + c];
+            f2 b[4];
+            int bu[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const uint8_t *row = lds_uv + ye.base[a];
+                int qu[4], qv[4];
+                f2 p[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    qu[k] = row[xe.off[k]];
+                    qv[k] = row[xe.off[k] + 1];
+                    p[k] = (f2){ (float)qu[k], (float)qv[k] };
+                }
+                b[a] = cubic4_pair(wx, wx, xe.c, xe.c, p, qu, qv);
+                bu[a] = (int)b[a].x;
+                bv[a] = (int)b[a].y;
+            }
+            const f2 v = cubic4_pair(wy, wy, ye.c, ye.c, b, bu, bv);
+            Uf[c] = v.x;
+            Vf[c] = v.y;
+        }
+    }
+    {
+        BXEntry xe[PXW];
+        float wx[PXW];
+#pragma unroll
+        for (int c = 0; c < PXW; c++) {
+            xe[c] = xtab[lx * PXW + c];
+            wx[c] = wxt[lx * PXW + c];
+        }
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const BYEntry ye = ytab[ly * PXH + r];
+            const float wy = wyt[ly * PXH + r];
+#pragma unroll
+            for (int c = 0; c < PXW; c += 2) { // horizontally adjacent pixel pair
+                f2 b[4];
+                int b0[4], b1[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const uint8_t *row = lds_y + ye.base[a];
+                    int q0[4], q1[4];
+                    f2 p[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        q0[k] = row[xe[c].off[k]];
+                        q1[k] = row[xe[c + 1].off[k]];
+                        p[k] = (f2){ (float)q0[k], (float)q1[k] };
+                    }
+                    b[a] = cubic4_pair(wx[c], wx[c + 1], xe[c].c, xe[c + 1].c, p, q0, q1);
+                    b0[a] = (int)b[a].x;
+                    b1[a] = (int)b[a].y;
+                }
+                const f2 v = cubic4_pair(wy, wy, ye.c, ye.c, b, b0, b1);
+                Yf[r][c] = v.x;
+                Yf[r][c + 1] = v.y;
+            }
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Persistent variant of the 2x2-tap kernel (opt-in, TSVPP_PERSIST=k workgroups per CU).  A fixed
 // grid of resident workgroups walks the tile list (tile = block + i * grid: neighbouring
 // workgroups still write neighbouring tiles).  LDS holds TWO tile sets; while set `cur` is blended,
@@ -1436,6 +1650,11 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             hipLaunchKernelGGL((vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes, stream, d, t);
             return hipGetLastError();
         }
+    } else if constexpr (MODE == M_BICUBIC) {
+        if (staged) {
+            hipLaunchKernelGGL((vpp_bicubic_kernel<OUT>), grid, block, lds_bytes, stream, d, t);
+            return hipGetLastError();
+        }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
             if (vec && d.area_direct && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
@@ -1557,6 +1776,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                             (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
                 if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
                     need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
+                if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights
+                    need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * (sizeof(BXEntry) + sizeof(float)) +
+                            (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * (sizeof(BYEntry) + sizeof(float));
                 if (need > kLdsBudget) continue;
                 staged = true;
                 lds_bytes = need;
