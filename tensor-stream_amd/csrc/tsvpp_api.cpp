@@ -145,7 +145,7 @@ struct tsvpp_ctx {
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
     int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
-    int nt_stores = 0, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
+    int nt_stores = -1, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
     float area_direct_min = 2.0f;   // TSVPP_AREA_DIRECT_MIN
@@ -292,7 +292,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     ctx->device = device;
     tsvpp_default_coeffs(&ctx->coeffs);
     if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
-    if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = (e[0] == '1');
+    if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = std::atoi(e); // 0 plain, 1 nt, 2 sc1; default -1 = per kernel
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);

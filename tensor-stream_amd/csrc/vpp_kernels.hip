@@ -348,10 +348,28 @@ __device__ __forceinline__ f2 norm255(f2 v) {
 }
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
+// Output store policy (LaunchDesc::nt_stores): 0 plain, 1 non-temporal, 2 `sc1` write-through.  The
+// output is written once and never re-read by the kernel, so it should not displace the input
+// lines in L2: measured on MI355X (tools/ab.sh TSVPP_NT=0/1/2) non-temporal stores gain 3-20 % on
+// the resize kernels, `sc1` 14 % on the colour-only fp32 kernel (25 MB written per 3 MB read) but
+// lose 36 % on 4-byte uint8 stores (each becomes its own fabric write).  launch_fused picks
+// accordingly; TSVPP_NT overrides.
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float e, int nt) {
     vf4 v = { a, b, c, e };
-    if (nt) __builtin_nontemporal_store(v, (vf4 *)p);
+    if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if (nt == 1) __builtin_nontemporal_store(v, (vf4 *)p);
     else *(vf4 *)p = v;
+}
+// same with a uniform base pointer and a 32-bit byte offset per lane (SGPR base + VGPR offset)
+__device__ __forceinline__ void st4o(uint8_t *base, uint32_t off, float a, float b, float c, float e, int nt) {
+    vf4 v = { a, b, c, e };
+    if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else if (nt == 1) __builtin_nontemporal_store(v, (vf4 *)(base + off));
+    else *(vf4 *)(base + off) = v;
+}
+__device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int nt) {
+    if (nt == 2) asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *(uint32_t *)(base + off) = v;
 }
 
 // One output row of this thread: 4 pixels -> 3 channels, converted and stored.
@@ -385,14 +403,14 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                 // uniform plane bases (SGPR pairs) + one 32-bit byte offset per lane
                 const uint32_t boff = pix * 4u;
                 uint8_t *b0 = (uint8_t *)o, *b1 = (uint8_t *)(o + plane), *b2 = (uint8_t *)(o + 2 * (size_t)plane);
-                st4((float *)(b0 + boff), c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
-                st4((float *)(b1 + boff), c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
-                st4((float *)(b2 + boff), c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
+                st4o(b0, boff, c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
+                st4o(b1, boff, c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
+                st4o(b2, boff, c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
             } else {
-                float *q = (float *)((uint8_t *)o + pix * 12u);
-                st4(q, c0[0].x, c1[0].x, c2[0].x, c0[0].y, nt);
-                st4(q + 4, c1[0].y, c2[0].y, c0[1].x, c1[1].x, nt);
-                st4(q + 8, c2[1].x, c0[1].y, c1[1].y, c2[1].y, nt);
+                const uint32_t q = pix * 12u;
+                st4o((uint8_t *)o, q, c0[0].x, c1[0].x, c2[0].x, c0[0].y, nt);
+                st4o((uint8_t *)o, q + 16u, c1[0].y, c2[0].y, c0[1].x, c1[1].x, nt);
+                st4o((uint8_t *)o, q + 32u, c2[1].x, c0[1].y, c1[1].y, c2[1].y, nt);
             }
         } else {
             const float v0[4] = { c0[0].x, c0[0].y, c0[1].x, c0[1].y }, v1[4] = { c1[0].x, c1[0].y, c1[1].x, c1[1].y },
@@ -415,15 +433,15 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
         const uint8_t v2[4] = { (uint8_t)(int)c2[0].x, (uint8_t)(int)c2[0].y, (uint8_t)(int)c2[1].x, (uint8_t)(int)c2[1].y };
         uint8_t *o = (uint8_t *)out;
         if constexpr (VEC) {
+            auto pk = [](uint8_t a, uint8_t b, uint8_t c, uint8_t e) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)e << 24); };
             if constexpr (PLANAR) {
-                *(uchar4 *)(o + pix) = make_uchar4(v0[0], v0[1], v0[2], v0[3]);
-                *(uchar4 *)(o + plane + pix) = make_uchar4(v1[0], v1[1], v1[2], v1[3]);
-                *(uchar4 *)(o + 2 * plane + pix) = make_uchar4(v2[0], v2[1], v2[2], v2[3]);
+                st1o(o, pix, pk(v0[0], v0[1], v0[2], v0[3]), nt);
+                st1o(o + plane, pix, pk(v1[0], v1[1], v1[2], v1[3]), nt);
+                st1o(o + 2 * (size_t)plane, pix, pk(v2[0], v2[1], v2[2], v2[3]), nt);
             } else {
-                uchar4 *q = (uchar4 *)(o + 3 * pix);
-                q[0] = make_uchar4(v0[0], v1[0], v2[0], v0[1]);
-                q[1] = make_uchar4(v1[1], v2[1], v0[2], v1[2]);
-                q[2] = make_uchar4(v2[2], v0[3], v1[3], v2[3]);
+                st1o(o, 3u * pix, pk(v0[0], v1[0], v2[0], v0[1]), nt);
+                st1o(o, 3u * pix + 4u, pk(v1[1], v2[1], v0[2], v1[2]), nt);
+                st1o(o, 3u * pix + 8u, pk(v2[2], v0[3], v1[3], v2[3]), nt);
             }
         } else {
             for (int c = 0; c < ncol; c++) {
@@ -1699,6 +1717,10 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
 
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream) {
     LaunchDesc d = din;
+    if (d.nt_stores < 0) { // per-kernel default
+        const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED);
+        d.nt_stores = (mode == M_NONE && f32) ? 2 : 1;
+    }
     // Candidate workgroup shapes, largest first; the staged kernels take the first whose source
     // footprint fits the LDS budget (several workgroups per CU must stay resident to overlap one
     // group's loads with another's arithmetic).
