@@ -94,12 +94,16 @@ def test_many_consumers_in_threads():
 def test_dump_sizes(tmp_path):
     r = make()
     r.start()
+    cwd = os.getcwd()
     os.chdir(tmp_path)
-    for _ in range(3):
-        r.dump(r.read())
-    r.dump(r.read(), name="named")
-    assert os.stat("default.yuv").st_size == 1920 * 1080 * 3 * 3 and os.path.isfile("named.yuv")
-    r.stop()
+    try:
+        for _ in range(3):
+            r.dump(r.read())
+        r.dump(r.read(), name="named")
+        assert os.stat("default.yuv").st_size == 1920 * 1080 * 3 * 3 and os.path.isfile("named.yuv")
+    finally:
+        os.chdir(cwd)
+        r.stop()
 
 
 def test_multiple_init_stop_cycles():

@@ -235,6 +235,26 @@ def test_area_dyadic_integer_kernel(vpp, oracle, src, dst):
           resize_type=AREA, fourcc=RGB24, planes=MERGED, normalization=False)
 
 
+def test_64_consumers_each_on_its_own_stream(oracle):
+    """C5's shape: 64 concurrent consumers of one GPU -- 64 pooled streams, conversions issued
+    back to back without any host synchronisation in between, results identical to the oracle."""
+    import tensor_stream as ts
+    v = ts.VideoProcessor(device=0, max_consumers=64)
+    frames = [synth_nv12(640, 360, seed=300 + i) for i in range(4)]
+    dev = [(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()) for y, uv in frames]
+    fp = ts.FrameParameters(width=320, height=180, resize_type=AREA, pixel_format=BGR24, planes_pos=PLANAR, normalization=True)
+    outs = [v.Convert(*dev[c % 4], fp, consumer=f"consumer{c}") for c in range(64)]
+    streams = {v.consumer_stream(f"consumer{c}") for c in range(64)}
+    assert len(streams) == 64
+    torch.cuda.synchronize()
+    refs = [oracle.convert(y, uv, dst=(320, 180), resize_type=AREA, fourcc=BGR24, planes=PLANAR, normalization=True)[0] for y, uv in frames]
+    for c, o in enumerate(outs):
+        assert ulp_diff(o.cpu().numpy().ravel(), refs[c % 4]) == 0
+    with pytest.raises(RuntimeError, match="-3"):
+        v.consumer_stream("consumer64")
+    v.Close()
+
+
 def test_consumer_pool_semantics(vpp):
     """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
     (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
