@@ -30,6 +30,7 @@ struct AreaTable {
     int rows = 0, taps = 0;
     AreaQRow *qdev = nullptr; // integer form, only if every weight is k / 2^shift and taps <= 8
     int shift = -1;
+    int uniform_sum = 0;      // > 0: every row of the integer table has this weight sum
 };
 
 // Integer form of a weight table if all weights are dyadic: w * 2^shift integral, shift <= 6.
@@ -241,6 +242,9 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     }
     std::vector<AreaQRow> q;
     if (quantise_area_rows(tab, t.rows, t.taps, q, t.shift)) {
+        t.uniform_sum = q[0].sum;
+        for (const AreaQRow &e : q)
+            if (e.sum != q[0].sum) t.uniform_sum = 0;
         if (hipMalloc((void **)&t.qdev, q.size() * sizeof(AreaQRow)) == hipSuccess &&
             hipMemcpy(t.qdev, q.data(), q.size() * sizeof(AreaQRow), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(t.qdev);
@@ -446,6 +450,9 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         if (tx.qdev && ty.qdev && (double)255 * ((double)pl.xr * (1 << tx.shift) + 1) * ((double)pl.yr * (1 << ty.shift) + 1) < 16777216.0) {
             d.qx = tx.qdev;
             d.qy = ty.qdev;
+            // one divisor for the whole frame -> exact integer division by a constant in the kernel
+            if (tx.uniform_sum > 0 && ty.uniform_sum > 0 && (long)tx.uniform_sum * ty.uniform_sum < 4096)
+                d.area_rcp = 1.0f / (float)(tx.uniform_sum * ty.uniform_sum);
         }
     }
     // crop = pointer arithmetic (reference src/Crop.cu:10-18: luma at (left + j, top + i), chroma

@@ -45,6 +45,7 @@ struct LaunchDesc {
     const float *patx, *paty;
     int nx, ny, rx, ry;
     const AreaQRow *qx, *qy; // non-null: dyadic AREA tables (integer box sums)
+    float area_rcp;          // != 0: every (column, row) pattern pair has the same divisor S = sum(wx) * sum(wy); this is 1 / S
     // grid decomposition (filled by launch_fused)
     int tiles_x, tiles_y, n_frames;
     int blocks_per_xcd; // ceil(total_tiles / 8)

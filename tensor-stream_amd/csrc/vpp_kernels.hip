@@ -1241,13 +1241,25 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
 // (int)( float(SUM) / float(SX*SY) ) with SUM = sum_a wy[a] * sum_b wx[b] * p[a][b] in integers --
 // and the inner sum over four packed source bytes is ONE v_dot4_u32_u8.  The box starts at an
 // arbitrary byte: v_alignbyte_b32 shifts the aligned LDS dwords so that tap 0 sits in byte 0.
+// SUM / S truncated, S = sx * sy.  The reference's IEEE division of the two exact floats followed by
+// truncation equals the integer quotient (the quotient is either an integer or at least 1/S away
+// from one, far more than the division's rounding error).  With one divisor for the whole frame
+// (rcp = 1/S, S < 4096) the quotient is floor((SUM + 0.5) * rcp): the half keeps exact multiples
+// above their integer, and the product's error (< 255 * 2^-22) cannot reach the next one.
+__device__ __forceinline__ float area_quot(uint32_t sum, int sx, int sy, float rcp) {
+    if (rcp != 0.0f) return __builtin_truncf(((float)sum + 0.5f) * rcp);
+    return __builtin_truncf((float)sum / (float)(sx * sy));
+}
 struct AXEntry { int off, sum; uint32_t w0, w1; };                // luma column: LDS offset, sum(wx), packed weights
 struct ACEntry { int off, sum; uint32_t wu[4]; int pad0, pad1; }; // chroma pair column: weights on even bytes
 struct AYEntry { int row, sum; uint32_t w0, w1; };                // output row: first staged row, sum(wy), packed weights
 
-template <int NW, int OUT>
+// RY > 0: the number of vertical taps is a compile-time constant (2 and 3 cover ratios up to 3): the row loops
+// unroll and the dependent LDS reads (row base -> dwords) of all rows are in flight together.
+template <int NW, int RY, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
+    const int ry = RY ? RY : d.ry;
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int nthreads = d.tx * d.ty;
@@ -1326,7 +1338,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         const AYEntry ye = cytab[ly];
         uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
         ACEntry ce[2] = { cxtab[lx * 2], cxtab[lx * 2 + 1] };
-        for (int a = 0; a < d.ry; a++) {
+#pragma unroll
+        for (int a = 0; a < ry; a++) {
             const uint32_t wy = ((a < 4 ? ye.w0 : ye.w1) >> (8 * (a & 3))) & 255u;
             const int rb = rbuv[ye.row + a];
 #pragma unroll
@@ -1347,9 +1360,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const float div = (float)(ce[c].sum * ye.sum);
-            Uf[c] = __builtin_truncf((float)su[c] / div);
-            Vf[c] = __builtin_truncf((float)sv[c] / div);
+            Uf[c] = area_quot(su[c], ce[c].sum, ye.sum, d.area_rcp);
+            Vf[c] = area_quot(sv[c], ce[c].sum, ye.sum, d.area_rcp);
         }
     }
     {
@@ -1360,7 +1372,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         for (int r = 0; r < PXH; r++) {
             const AYEntry ye = ytab[ly * PXH + r];
             uint32_t sum[PXW] = { 0, 0, 0, 0 };
-            for (int a = 0; a < d.ry; a++) {
+#pragma unroll
+            for (int a = 0; a < ry; a++) {
                 const uint32_t wy = ((a < 4 ? ye.w0 : ye.w1) >> (8 * (a & 3))) & 255u;
                 const int rb = rby[ye.row + a];
 #pragma unroll
@@ -1374,7 +1387,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
                 }
             }
 #pragma unroll
-            for (int c = 0; c < PXW; c++) Yf[r][c] = __builtin_truncf((float)sum[c] / (float)(xe[c].sum * ye.sum));
+            for (int c = 0; c < PXW; c++) Yf[r][c] = area_quot(sum[c], xe[c].sum, ye.sum, d.area_rcp);
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
@@ -1467,9 +1480,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const float div = (float)(qx[c].sum * qy.sum);
-            Uf[c] = __builtin_truncf((float)su[c] / div);
-            Vf[c] = __builtin_truncf((float)sv[c] / div);
+            Uf[c] = area_quot(su[c], qx[c].sum, qy.sum, d.area_rcp);
+            Vf[c] = area_quot(sv[c], qx[c].sum, qy.sum, d.area_rcp);
         }
     }
     {
@@ -1503,7 +1515,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
                 }
             }
 #pragma unroll
-            for (int c = 0; c < PXW; c++) Yf[r][c] = __builtin_truncf((float)sum[c] / (float)(xs[c] * qy.sum));
+            for (int c = 0; c < PXW; c++) Yf[r][c] = area_quot(sum[c], xs[c], qy.sum, d.area_rcp);
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
@@ -1681,8 +1693,13 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 return hipGetLastError();
             }
             if (staged && d.qx && d.qy) {
-                if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, OUT>), grid, block, lds_bytes, stream, d, t);
-                else hipLaunchKernelGGL((vpp_area_dyadic_kernel<2, OUT>), grid, block, lds_bytes, stream, d, t);
+                if (d.rx <= 4) {
+                    if (d.ry == 2) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 2, OUT>), grid, block, lds_bytes, stream, d, t);
+                    else if (d.ry == 3) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 3, OUT>), grid, block, lds_bytes, stream, d, t);
+                    else hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 0, OUT>), grid, block, lds_bytes, stream, d, t);
+                } else {
+                    hipLaunchKernelGGL((vpp_area_dyadic_kernel<2, 0, OUT>), grid, block, lds_bytes, stream, d, t);
+                }
                 return hipGetLastError();
             }
         }
