@@ -150,6 +150,7 @@ struct tsvpp_ctx {
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
     float area_direct_min = 2.0f;   // TSVPP_AREA_DIRECT_MIN
+    int rpt = 2;                    // TSVPP_RPT
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
     // NV12 intermediates for the two-pass formats, one grow-only buffer per stream
@@ -300,6 +301,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     {
         hipDeviceProp_t prop;
@@ -431,6 +433,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.ablate = ctx->ablate;
     d.persist = ctx->persist;
     d.dma = ctx->dma;
+    d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
     d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {

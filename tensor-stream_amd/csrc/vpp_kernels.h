@@ -50,6 +50,7 @@ struct LaunchDesc {
     int tiles_x, tiles_y, n_frames;
     int blocks_per_xcd; // ceil(total_tiles / 8)
     int tx, ty, tx_shift; // workgroup = tx x ty thread tiles of 4 x 2 output pixels
+    int rpt;              // row pairs per thread (1; 2 in the 2x2-tap kernel: thread tile 4 x 4)
     // LDS staging bounds (staged kernel): max source bytes per row, rows, 16-byte chunks per row
     int lds_span_y, lds_rows_y, lds_cpr_y;
     int lds_span_uv, lds_rows_uv, lds_cpr_uv;
@@ -63,6 +64,7 @@ struct LaunchDesc {
     int shape_tx, shape_ty; // != 0: force the workgroup shape
     int area_direct;        // (launch_fused) dyadic AREA straight from global memory
     float area_direct_min;  // use it when both ratios are >= this (0 = never)
+    int rpt_pref;           // preferred row pairs per thread for the 2x2-tap kernel (TSVPP_RPT)
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)

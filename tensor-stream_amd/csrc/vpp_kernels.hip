@@ -618,9 +618,9 @@ template <int MODE>
 __device__ __forceinline__ Footprint tile_footprint(const LaunchDesc &d, const TileId &id) {
     Footprint f;
     f.j_first = id.tx * d.tx * PXW;
-    f.i_first = id.ty * d.ty * PXH;
+    f.i_first = id.ty * d.ty * PXH * d.rpt;
     f.j_last = min(f.j_first + d.tx * PXW, d.dst_w) - 1;
-    f.i_last = min(f.i_first + d.ty * PXH, d.dst_h) - 1;
+    f.i_last = min(f.i_first + d.ty * PXH * d.rpt, d.dst_h) - 1;
     const int cw = d.src_w >> 1, chh = d.src_h >> 1;
     axis_span<MODE>(f.j_first, f.j_last, d.xr, d.src_w, d.rx, f.xlo, f.xhi);
     axis_span<MODE>(f.i_first, f.i_last, d.yr, d.src_h, d.ry, f.ylo, f.yhi);
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int nthreads = d.tx * d.ty;
-    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const int tw = d.tx * PXW, th = d.ty * PXH * d.rpt;
     const Footprint f = tile_footprint<MODE>(d, id);
     const int cw = d.src_w >> 1, chh = d.src_h >> 1;
 
@@ -948,10 +948,14 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     }
 
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-
-    bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[id.frame], i0, j0);
+    const int j0 = f.j_first + lx * PXW;
+    if (j0 >= d.dst_w) return;
+    // thread tile = 4 columns x (2 * rpt) rows: the tile decode, the staging set-up and the table build are
+    // paid once per 8 * rpt pixels
+    for (int rp = 0; rp < d.rpt; rp++) {
+        const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
+        if (i0 < d.dst_h) bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1734,6 +1738,7 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
 
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream) {
     LaunchDesc d = din;
+    d.rpt = 1;
     if (d.nt_stores < 0) { // per-kernel default
         const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED);
         d.nt_stores = (mode == M_NONE && f32) ? 2 : 1;
@@ -1789,10 +1794,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
+            const int rpt = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.rpt_pref >= 1 && d.rpt_pref <= 8 && !d.persist) ? d.rpt_pref : 1;
             const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
-            const int rows_y = span_bound(mode, sh[1] * PXH, d.yr, d.ry);
+            const int rows_y = span_bound(mode, sh[1] * PXH * rpt, d.yr, d.ry);
             const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
-            const int rows_uv = span_bound(mode, sh[1] * PXH / 2, d.yr, d.ry);
+            const int rows_uv = span_bound(mode, sh[1] * PXH * rpt / 2, d.yr, d.ry);
             const int nthreads = sh[0] * sh[1];
             // per shape: the LDS-DMA layout first (power-of-two chunks per row, rows padded to whole
             // rounds), then the compact register-staged layout
@@ -1814,7 +1820,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
                             (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
                 if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
-                    need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(YEntry);
+                    need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(YEntry);
                 if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights
                     need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * (sizeof(BXEntry) + sizeof(float)) +
                             (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * (sizeof(BYEntry) + sizeof(float));
@@ -1823,6 +1829,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                 lds_bytes = need;
                 d.tx = sh[0];
                 d.ty = sh[1];
+                d.rpt = rpt;
                 d.lds_span_y = span_y;
                 d.lds_rows_y = rows_alloc_y;
                 d.lds_cpr_y = cpr_y;
@@ -1838,7 +1845,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (!staged) d.dma = 0;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     d.tx_shift = slot_shift_for(d.tx);
-    const int tile_w = d.tx * PXW, tile_h = d.ty * PXH;
+    const int tile_w = d.tx * PXW, tile_h = d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
