@@ -1794,7 +1794,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
-            const int rpt = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.rpt_pref >= 1 && d.rpt_pref <= 8 && !d.persist) ? d.rpt_pref : 1;
+            int rpt = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.rpt_pref >= 1 && d.rpt_pref <= 8 && !d.persist) ? d.rpt_pref : 1;
+            // taller thread tiles only while the launch still has at least two full rounds of workgroups
+            // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
+            while (rpt > 1) {
+                const long wgs = (long)((d.dst_w + sh[0] * PXW - 1) / (sh[0] * PXW)) * ((d.dst_h + sh[1] * PXH * rpt - 1) / (sh[1] * PXH * rpt)) * d.n_frames;
+                if (wgs >= 16L * d.num_cus) break;
+                rpt--;
+            }
             const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
             const int rows_y = span_bound(mode, sh[1] * PXH * rpt, d.yr, d.ry);
             const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
