@@ -255,6 +255,40 @@ def test_64_consumers_each_on_its_own_stream(oracle):
     v.Close()
 
 
+def test_hip_graph_capture_and_replay(vpp, oracle):
+    """The conversion allocates, frees and synchronises nothing (after tsvpp_prepare), so a whole batch can be captured
+    in a HIP graph once and replayed on new frame contents -- the reference's Convert (cudaMalloc/cudaFree per frame)
+    cannot be captured at all."""
+    import tensor_stream as ts
+    n = 6
+    frames_a = [synth_nv12(640, 360, seed=400 + i) for i in range(n)]
+    frames_b = [synth_nv12(640, 360, seed=500 + i) for i in range(n)]
+    ys = torch.from_numpy(np.stack([f[0] for f in frames_a])).cuda()
+    uvs = torch.from_numpy(np.stack([f[1] for f in frames_a])).cuda()
+    fp = ts.FrameParameters(width=426, height=240, resize_type=AREA, pixel_format=BGR24, planes_pos=PLANAR, normalization=True)
+    vpp.prepare(fp, 640, 360)                       # AREA tables built outside the capture
+    out = vpp._alloc(fp.parameters, 640, 360, n)
+    batch = vpp.make_batch(ys, uvs, fp, out=out)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        vpp.run_batch(batch, s.cuda_stream)         # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        vpp.run_batch(batch, torch.cuda.current_stream().cuda_stream)
+    ys.copy_(torch.from_numpy(np.stack([f[0] for f in frames_b])).cuda())
+    uvs.copy_(torch.from_numpy(np.stack([f[1] for f in frames_b])).cuda())
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    for i in range(n):
+        ref, _, _ = oracle.convert(frames_b[i][0], frames_b[i][1], dst=(426, 240), resize_type=AREA, fourcc=BGR24, planes=PLANAR,
+                                   normalization=True)
+        assert ulp_diff(o[i].ravel(), ref) == 0
+
+
 def test_consumer_pool_semantics(vpp):
     """findFree: a name keeps its stream; a 6th name on a 5-slot pool is VREADER_ERROR
     (reference include/Common.h:225-237, src/VideoProcessor.cpp:100-103)."""
