@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets")
+    ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -111,6 +112,12 @@ def main():
     from tensor_stream import parallel
 
     spec = list(WORKLOADS[args.workload])
+    if args.custom:
+        a = args.custom.split(":")
+        sw, sh = (int(x) for x in a[0].split("x"))
+        dw, dh = (int(x) for x in a[1].split("x"))
+        spec = [sw, sh, (sw + 255) // 256 * 256, (0, 0, 0, 0), (dw, dh), a[2], a[3], a[4], a[5] == "1"]
+        args.workload = "custom"
     if args.resize:
         spec[5] = args.resize
     spec = tuple(spec)

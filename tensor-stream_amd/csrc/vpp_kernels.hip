@@ -1755,6 +1755,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     constexpr size_t kLdsBudget = 40 * 1024;
     bool staged = false;
     size_t lds_bytes = 0;
+    auto workgroups = [&](const int *sh, int rpt) {
+        return (long)((d.dst_w + sh[0] * PXW - 1) / (sh[0] * PXW)) * ((d.dst_h + sh[1] * PXH * rpt - 1) / (sh[1] * PXH * rpt)) * d.n_frames;
+    };
     d.tx = shapes[0][0];
     d.ty = shapes[0][1];
     if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
@@ -1797,11 +1800,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             int rpt = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.rpt_pref >= 1 && d.rpt_pref <= 8 && !d.persist) ? d.rpt_pref : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
-            while (rpt > 1) {
-                const long wgs = (long)((d.dst_w + sh[0] * PXW - 1) / (sh[0] * PXW)) * ((d.dst_h + sh[1] * PXH * rpt - 1) / (sh[1] * PXH * rpt)) * d.n_frames;
-                if (wgs >= 16L * d.num_cus) break;
-                rpt--;
-            }
+            while (rpt > 1 && workgroups(sh, rpt) < 16L * d.num_cus) rpt--;
             const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
             const int rows_y = span_bound(mode, sh[1] * PXH * rpt, d.yr, d.ry);
             const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
