@@ -1793,7 +1793,13 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     } else {
         d.point_kind = PK_NONE;
     }
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct) {
+    // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
+    // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
+    // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
+    // 224^2 / 300^2 / 640^2, 4K -> 640x360): BILINEAR gathers win from xr*yr ~ 16 (3.5x at 41), BICUBIC from ~ 30.
+    const float ratio_area = d.xr * d.yr;
+    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 16.0f) || (mode == M_BICUBIC && ratio_area >= 30.0f);
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
