@@ -31,6 +31,8 @@ struct AreaTable {
     AreaQRow *qdev = nullptr; // integer form, only if every weight is k / 2^shift and taps <= 8
     int shift = -1;
     int uniform_sum = 0;      // > 0: every row of the integer table has this weight sum
+    float *dev4 = nullptr;    // the float rows zero-padded to a multiple of four taps
+    int nk = 0;               // taps4 = 4 * nk
 };
 
 // Integer form of a weight table if all weights are dyadic: w * 2^shift integral, shift <= 6.
@@ -241,6 +243,17 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
         (void)hipFree(t.dev);
         return (int)e;
     }
+    {
+        t.nk = (t.taps + 3) / 4;
+        std::vector<float> pad((size_t)t.rows * 4 * t.nk, 0.0f);
+        for (int r = 0; r < t.rows; r++)
+            for (int k = 0; k < t.taps; k++) pad[(size_t)r * 4 * t.nk + k] = tab[(size_t)r * t.taps + k];
+        if (hipMalloc((void **)&t.dev4, pad.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(t.dev4, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(t.dev);
+            return TSVPP_ERROR;
+        }
+    }
     std::vector<AreaQRow> q;
     if (quantise_area_rows(tab, t.rows, t.taps, q, t.shift)) {
         t.uniform_sum = q[0].sum;
@@ -332,6 +345,7 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
     for (auto &a : ctx->area) {
         if (a.second.dev) (void)hipFree(a.second.dev);
         if (a.second.qdev) (void)hipFree(a.second.qdev);
+        if (a.second.dev4) (void)hipFree(a.second.dev4);
     }
     delete ctx;
 }
@@ -448,6 +462,10 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.paty = ty.dev;
         d.ny = ty.rows;
         d.ry = ty.taps;
+        d.patx4 = tx.dev4;
+        d.nkx = tx.nk;
+        d.paty4 = ty.dev4;
+        d.nky = ty.nk;
         // integer box sums are exact (and equal to the reference's float accumulation) while
         // 255 * sum(wx) * sum(wy) stays below 2^24
         if (tx.qdev && ty.qdev && (double)255 * ((double)pl.xr * (1 << tx.shift) + 1) * ((double)pl.yr * (1 << ty.shift) + 1) < 16777216.0) {

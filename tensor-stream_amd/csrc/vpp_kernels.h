@@ -45,6 +45,8 @@ struct LaunchDesc {
     const float *patx, *paty;
     int nx, ny, rx, ry;
     const AreaQRow *qx, *qy; // non-null: dyadic AREA tables (integer box sums)
+    const float *patx4, *paty4; // float weight rows zero-padded to 4 * nkx / 4 * nky entries (direct float AREA kernel)
+    int nkx, nky;
     float area_rcp;          // != 0: every (column, row) pattern pair has the same divisor S = sum(wx) * sum(wy); this is 1 / S
     // grid decomposition (filled by launch_fused)
     int tiles_x, tiles_y, n_frames;

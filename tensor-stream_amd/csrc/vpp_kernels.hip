@@ -1413,12 +1413,14 @@ typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 // not the plane's last one, so the few bytes past the box still belong to the plane); otherwise
 // dword by dword, and a dword the box does not reach is re-pointed at dword 0 -- nothing is read
 // beyond the dword of the last needed byte.
-// `plane` is the frame's (wave-uniform) plane pointer and `off` a 32-bit byte offset: the loads use
-// the SGPR-base + VGPR-offset addressing mode; `pm` = plane pointer & 3 (uniform).
+// `plane` is the frame's (wave-uniform) plane pointer rounded DOWN to a dword, `pm` the bytes it was
+// rounded by and `off` a 32-bit byte offset from the true pointer: the loads use the SGPR-base +
+// VGPR-offset addressing mode and the offset (off + pm) & ~3 can never go negative.
 template <int N, bool WIDE>
 __device__ __forceinline__ void load_span(const uint8_t *plane, uint32_t pm, uint32_t off, int nbytes, uint32_t (&dw)[N + 1], uint32_t &sh) {
-    sh = (pm + off) & 3u;
-    const uint32_t *p = (const uint32_t *)(plane + (off - sh)); // aligned dword of the first byte
+    const uint32_t o = off + pm;
+    sh = o & 3u;
+    const uint32_t *p = (const uint32_t *)(plane + (o - sh)); // aligned dword of the first byte
     if constexpr (WIDE) {
         if constexpr (N == 1) {
             const u32x2a4 v = *(const u32x2a4 *)p;
@@ -1446,8 +1448,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-    const uint8_t *Y = t.y[id.frame], *UV = t.uv[id.frame];
-    const uint32_t ym = (uint32_t)((uintptr_t)Y & 3), uvm = (uint32_t)((uintptr_t)UV & 3);
+    const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
+    const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
     const int ci = i0 >> 1, cj0 = j0 >> 1;
 
     float Uf[2], Vf[2], Yf[PXH][PXW];
@@ -1520,6 +1522,131 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
             }
 #pragma unroll
             for (int c = 0; c < PXW; c++) Yf[r][c] = area_quot(sum[c], xs[c], qy.sum, d.area_rcp);
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
+// AREA down-scale with arbitrary (non-dyadic) weights at ratios >= 2, straight from global memory.
+// The reference's float accumulation order (rows outer, taps inner; src/Resize.cu:164-173) is kept
+// per value, so sums are bit-identical: sum += float(tap) * (wx[b] * wy[a]); div += wx[b] * wy[a].
+// Same memory scheme as vpp_area_direct_kernel (per-pixel aligned dwords + v_alignbyte so that tap 0
+// is byte 0); the weight rows are zero-padded to 4 * NK taps, and a zero weight adds exactly 0 to
+// both accumulators, so four taps are always processed per shifted dword.  Pixel pairs / (U, V)
+// pairs share the packed VALU.
+typedef float vf4a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int NK, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
+    const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
+    const int ci = i0 >> 1, cj0 = j0 >> 1;
+
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+    { // chroma: U and V of one pair share every weight
+        const float *wyrow = d.paty4 + (ci % d.ny) * 4 * d.nky;
+        const int y0 = (int)(d.yr * (float)ci);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int x0 = 2 * (int)(d.xr * (float)(cj0 + c));
+            const float *wxrow = d.patx4 + ((cj0 + c) % d.nx) * 4 * NK;
+            vf4 wx[NK];
+#pragma unroll
+            for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
+            f2 acc = { 0.0f, 0.0f };
+            float div = 0.0f;
+            for (int a = 0; a < d.ry; a++) {
+                const float wy = wyrow[a];
+                const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_uv + (uint32_t)x0;
+                uint32_t dw[2 * NK + 1], sh;
+                const bool wide = (y0 + a) < (d.src_h >> 1) - 1;
+                if constexpr (NK == 1) {
+                    if (wide) load_span<2, true>(UV, uvm, row, 2 * d.rx, dw, sh); else load_span<2, false>(UV, uvm, row, 2 * d.rx, dw, sh);
+                } else {
+                    sh = (uvm + row) & 3u; // 2 * NK + 1 dwords, one by one (spans of 4-6 dwords)
+                    const uint32_t *p = (const uint32_t *)(UV + (row + uvm - sh));
+#pragma unroll
+                    for (int k = 0; k <= 2 * NK; k++) dw[k] = p[(wide || 4 * k < (int)sh + 2 * d.rx) ? k : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const uint32_t v0 = __builtin_amdgcn_alignbyte(dw[2 * k + 1], dw[2 * k], sh);     // U0 V0 U1 V1
+                    const uint32_t v1 = __builtin_amdgcn_alignbyte(dw[2 * k + 2], dw[2 * k + 1], sh); // U2 V2 U3 V3
+                    const float wv[4] = { wx[k].x, wx[k].y, wx[k].z, wx[k].w };
+                    const uint32_t vv[2] = { v0, v1 };
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t q = vv[b >> 1] >> (16 * (b & 1));
+                        const float wgt = wv[b] * wy;
+                        div = div + wgt;
+                        acc = acc + (f2){ (float)(q & 255), (float)((q >> 8) & 255) } * (f2){ wgt, wgt };
+                    }
+                }
+            }
+            Uf[c] = __builtin_truncf(acc.x / div);
+            Vf[c] = __builtin_truncf(acc.y / div);
+        }
+    }
+    { // luma: horizontally adjacent pixel pairs share the packed VALU
+        int x0[PXW];
+        vf4 wx[PXW][NK];
+#pragma unroll
+        for (int c = 0; c < PXW; c++) {
+            x0[c] = (int)(d.xr * (float)(j0 + c));
+            const float *wxrow = d.patx4 + ((j0 + c) % d.nx) * 4 * NK;
+#pragma unroll
+            for (int k = 0; k < NK; k++) wx[c][k] = *(const vf4a4 *)(wxrow + 4 * k);
+        }
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const float *wyrow = d.paty4 + ((i0 + r) % d.ny) * 4 * d.nky;
+            const int y0 = (int)(d.yr * (float)(i0 + r));
+            f2 acc[2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } }, div[2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+            for (int a = 0; a < d.ry; a++) {
+                const float wy = wyrow[a];
+                const uint32_t rowo = (uint32_t)(y0 + a) * (uint32_t)d.pitch_y;
+                const bool wide = (y0 + a) < d.src_h - 1;
+                uint32_t dw[PXW][NK + 1], sh[PXW];
+#pragma unroll
+                for (int c = 0; c < PXW; c++) {
+                    if constexpr (NK <= 2) {
+                        if (wide) load_span<NK, true>(Y, ym, rowo + (uint32_t)x0[c], d.rx, dw[c], sh[c]);
+                        else load_span<NK, false>(Y, ym, rowo + (uint32_t)x0[c], d.rx, dw[c], sh[c]);
+                    } else {
+                        sh[c] = (ym + rowo + (uint32_t)x0[c]) & 3u;
+                        const uint32_t *p = (const uint32_t *)(Y + (rowo + (uint32_t)x0[c] + ym - sh[c]));
+#pragma unroll
+                        for (int k = 0; k <= NK; k++) dw[c][k] = p[(wide || 4 * k < (int)sh[c] + d.rx) ? k : 0];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const uint32_t va = __builtin_amdgcn_alignbyte(dw[2 * p][k + 1], dw[2 * p][k], sh[2 * p]);
+                        const uint32_t vb = __builtin_amdgcn_alignbyte(dw[2 * p + 1][k + 1], dw[2 * p + 1][k], sh[2 * p + 1]);
+                        const float wa[4] = { wx[2 * p][k].x, wx[2 * p][k].y, wx[2 * p][k].z, wx[2 * p][k].w };
+                        const float wb[4] = { wx[2 * p + 1][k].x, wx[2 * p + 1][k].y, wx[2 * p + 1][k].z, wx[2 * p + 1][k].w };
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const f2 wgt = (f2){ wa[b], wb[b] } * (f2){ wy, wy };
+                            div[p] = div[p] + wgt;
+                            acc[p] = acc[p] + (f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) } * wgt;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                Yf[r][2 * p] = __builtin_truncf(acc[p].x / div[p].x);
+                Yf[r][2 * p + 1] = __builtin_truncf(acc[p].y / div[p].y);
+            }
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
@@ -1691,9 +1818,15 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
         }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
-            if (vec && d.area_direct && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
+            if (vec && d.area_direct == 1 && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
                 if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_direct_kernel<1, OUT>), grid, block, 0, stream, d, t);
                 else hipLaunchKernelGGL((vpp_area_direct_kernel<2, OUT>), grid, block, 0, stream, d, t);
+                return hipGetLastError();
+            }
+            if (vec && d.area_direct == 2 && !d.force_gather) { // large non-dyadic ratios: float sums straight from global memory
+                if (d.nkx == 1) hipLaunchKernelGGL((vpp_area_direct_float_kernel<1, OUT>), grid, block, 0, stream, d, t);
+                else if (d.nkx == 2) hipLaunchKernelGGL((vpp_area_direct_float_kernel<2, OUT>), grid, block, 0, stream, d, t);
+                else hipLaunchKernelGGL((vpp_area_direct_float_kernel<3, OUT>), grid, block, 0, stream, d, t);
                 return hipGetLastError();
             }
             if (staged && d.qx && d.qy) {
@@ -1763,6 +1896,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
         d.yr >= d.area_direct_min)
         d.area_direct = 1;
+    else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
+             d.yr >= d.area_direct_min && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
+        d.area_direct = 2; // float weights
     else
         d.area_direct = 0;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);

@@ -255,6 +255,30 @@ def test_64_consumers_each_on_its_own_stream(oracle):
     v.Close()
 
 
+@pytest.mark.parametrize("src,dst", [((1920, 1080), (224, 224)),   # 8.57 x 4.82: 9 taps -> three weight quads
+                                     ((1920, 1080), (300, 300)),   # 6.4 x 3.6
+                                     ((1920, 1080), (640, 400)),   # 3 x 2.7: one quad
+                                     ((1282, 722), (224, 224)),    # unaligned pitch, 5.72 x 3.22
+                                     ((1920, 1080), (160, 90))])   # 12 x 12 (dyadic -> integer kernel; 12 taps)
+def test_area_large_ratio_direct_kernels(vpp, oracle, src, dst):
+    """Large-ratio AREA reads its boxes straight from global memory (float weights when they are not dyadic);
+    the accumulation order is the reference's, so results stay bit-identical."""
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0] + 1, pitch=src[0] + 2)
+    check(vpp, oracle, y, uv, width=src[0], dst=dst, resize_type=AREA, fourcc=RGB24, planes=PLANAR, normalization=True)
+    check(vpp, oracle, y, uv, width=src[0], crop=(6, 4, src[0] - 4, src[1] - 2), dst=dst, resize_type=AREA, fourcc=BGR24, planes=MERGED)
+
+
+def test_area_direct_kernels_with_misaligned_crop_origin(vpp, oracle):
+    """Regression: the direct kernels address aligned dwords from a dword-aligned base; an odd crop origin makes the
+    plane pointer itself misaligned (first byte of the first row sits BEFORE the first aligned dword of the offset)."""
+    y, uv = synth_nv12(1920, 1080, seed=77)
+    for crop, dst in [((1, 2, 1601, 902), (160, 90)),      # ratio 10: dyadic integer kernel
+                      ((3, 1, 1603, 901), (320, 180)),     # ratio 5
+                      ((1, 1, 1501, 901), (224, 224)),     # non-dyadic float kernel
+                      ((2, 0, 1502, 900), (224, 224))]:
+        check(vpp, oracle, y, uv, crop=crop, dst=dst, resize_type=AREA, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
 def test_hip_graph_capture_and_replay(vpp, oracle):
     """The conversion allocates, frees and synchronises nothing (after tsvpp_prepare), so a whole batch can be captured
     in a HIP graph once and replayed on new frame contents -- the reference's Convert (cudaMalloc/cudaFree per frame)
