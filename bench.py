@@ -100,12 +100,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = local if world > 1 else 0
+    dev = local if dist is not None else 0
     torch.cuda.set_device(dev)
 
     import tensor_stream as ts

@@ -19,7 +19,7 @@ def shard_streams(n_streams, rank, world):
 def broadcast_coeff_block(block, dist, device=None):
     """Broadcast rank 0's 8-float block; returns the received list.  `dist` is torch.distributed
     (initialised) or None for a single process."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [float(x) for x in block]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
