@@ -36,16 +36,16 @@ WORKLOADS = {
     "c5": (3840, 2160, 3840, (0, 0, 0, 0), (640, 360), "AREA", "BGR24", "PLANAR", True),
 }
 RESIZE = {"NEAREST": 0, "BILINEAR": 1, "BICUBIC": 2, "AREA": 3}
-FOURCC = {"RGB24": 1, "BGR24": 2}
+FOURCC = {"Y800": 0, "RGB24": 1, "BGR24": 2, "NV12": 3, "UYVY": 4, "YUV444": 5, "HSV": 6}
 PLANES = {"PLANAR": 0, "MERGED": 1}
 
 
-def algorithmic_bytes(src_w, src_h, crop, dst, norm):
-    """ROI_w*ROI_h*3/2 + dst_w*dst_h*3*sizeof(T)."""
+def algorithmic_bytes(src_w, src_h, crop, dst, norm, channels=3.0, luma_only=False):
+    """ROI_w*ROI_h*3/2 + dst_w*dst_h*channels*sizeof(T) (Y800 does not read the chroma plane)."""
     cw, ch = crop[2] - crop[0], crop[3] - crop[1]
     roi_w, roi_h = (cw, ch) if (0 < cw < src_w and 0 < ch < src_h) else (src_w, src_h)
     dw, dh = dst if (dst[0] and dst[1]) else (roi_w, roi_h)
-    return roi_w * roi_h * 3 // 2 + dw * dh * 3 * (4 if norm else 1)
+    return roi_w * roi_h * (2 if luma_only else 3) // 2 + int(dw * dh * channels) * (4 if norm else 1)
 
 
 def cpu_baseline(spec, budget_s=12.0):
@@ -138,7 +138,8 @@ def main():
         uvs = torch.randint(0, 256, (B, src_h // 2, pitch), dtype=torch.uint8, device="cuda", generator=g)
         out = vpp._alloc(fp.parameters, src_w, src_h, B)
         sets.append((ys, uvs, out))
-    bytes_per_frame = algorithmic_bytes(src_w, src_h, crop, dst, norm)
+    chans = {0: 1.0, 3: 1.5, 4: 2.0}.get(FOURCC[fcc], 3.0)
+    bytes_per_frame = algorithmic_bytes(src_w, src_h, crop, dst, norm or fcc == "HSV", chans, luma_only=(fcc == "Y800"))
     ws_mib = sum(a.numel() * a.element_size() for s in sets for a in s) / 2**20
 
     parity = "skipped"

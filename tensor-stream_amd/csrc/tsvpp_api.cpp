@@ -488,7 +488,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // Formats other than RGB24/BGR24: the reference feeds its other colour kernels with
     // the resized NV12; here pass 1 (only if there is a resize) writes that intermediate with the
     // fused kernel, pass 2 converts it.  Crop alone needs no pass 1: it is pointer arithmetic.
-    const bool two_pass = pl.fourcc != TSVPP_RGB24 && pl.fourcc != TSVPP_BGR24;
+    const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
     uint8_t *scratch = nullptr;
     size_t frame_scratch = 0;
     if (two_pass && pl.mode != M_NONE) {
@@ -506,43 +506,43 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         scratch = slot.first;
     }
     OutKind out_kind = pl.out;
+    if (pl.fourcc == TSVPP_Y800) out_kind = pl.f32 ? O_Y800_F32 : O_Y800_U8;
+    else if (pl.fourcc == TSVPP_NV12) out_kind = pl.f32 ? O_NV12_F32 : O_NV12_U8;
+    else if (pl.fourcc == TSVPP_HSV) out_kind = O_HSV_F32;
     if (two_pass) {
         out_kind = O_NV12_U8;
         vec = (pl.dst_w % 4) == 0; // scratch frames are 256-byte aligned
+        if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     }
-    for (int base = 0; base < n && !(two_pass && pl.mode == M_NONE); base += TSVPP_MAX_BATCH) {
+    for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
         FrameTable t;
-        for (int f = 0; f < cnt; f++) {
-            t.y[f] = in[base + f].y + y_off;
-            t.uv[f] = in[base + f].uv + uv_off;
-            t.out[f] = two_pass ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
-        }
-        for (int f = cnt; f < TSVPP_MAX_BATCH; f++) {
+        for (int f = 0; f < TSVPP_MAX_BATCH; f++) {
             t.y[f] = nullptr;
             t.uv[f] = nullptr;
             t.out[f] = nullptr;
         }
+        for (int f = 0; f < cnt; f++) {
+            t.y[f] = in[base + f].y + y_off;
+            t.uv[f] = in[base + f].uv + uv_off;
+            t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
+        }
         d.n_frames = cnt;
-        hipError_t e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (two_pass) {
-        for (int f = 0; f < n; f++) {
-            const uint8_t *fy, *fuv;
-            int fpy, fpuv;
+        if (!(two_pass && pl.mode == M_NONE)) {
+            hipError_t e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (two_pass) {
+            int fpy = pitch_y, fpuv = pitch_uv;
             if (pl.mode != M_NONE) { // resized intermediate: tight, pitch = width (as the reference's)
-                fy = scratch + (size_t)f * frame_scratch;
-                fuv = fy + (size_t)pl.dst_w * pl.dst_h;
+                for (int f = 0; f < cnt; f++) {
+                    t.y[f] = scratch + (size_t)(base + f) * frame_scratch;
+                    t.uv[f] = t.y[f] + (size_t)pl.dst_w * pl.dst_h;
+                    t.out[f] = outs[base + f];
+                }
                 fpy = fpuv = pl.dst_w;
-            } else {
-                fy = in[f].y + y_off;
-                fuv = in[f].uv + uv_off;
-                fpy = pitch_y;
-                fpuv = pitch_uv;
             }
-            hipError_t e = launch_format(pl.fourcc, pl.f32, p->normalization != 0 || pl.fourcc == TSVPP_HSV, fy, fuv, fpy, fpuv, pl.dst_w,
-                                         pl.dst_h, outs[f], ctx->coeffs, (hipStream_t)stream);
+            hipError_t e = launch_format(pl.fourcc, pl.f32, t, cnt, fpy, fpuv, pl.dst_w, pl.dst_h, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
     }

@@ -1,11 +1,9 @@
-// vpp_formats.hip -- the reference's other output formats, from (already cropped / resized) NV12:
-//   Y800      reference src/ColorConversion.cu:95-105
-//   NV12      (planes packed back to back)  :211-233
-//   UYVY      4:2:0 -> 4:2:2, vertical (-1, 9, 9, -1)/16 chroma filter on odd chroma rows  :107-127, 177-209
+// vpp_formats.hip -- the two output formats whose chroma filters reach across rows / pixel pairs and
+// therefore run as a second pass over the (already cropped / resized) NV12:
+//   UYVY      4:2:0 -> 4:2:2, vertical (-1, 9, 9, -1)/16 chroma filter on odd chroma rows  reference src/ColorConversion.cu:107-127, 177-209
 //   YUV444    UYVY -> planar 4:4:4, horizontal (-1, 9, 9, -1)/16 filter on odd pixels      :129-173
-//   HSV       normalised RGB -> HSV                                                           :235-278, 357-370
-// These are the "next" rows of SURVEY.md 8(f): one straightforward kernel each (thread = one
-// horizontal pixel pair), not tuned.  Same arithmetic contract as vpp_kernels.hip: plain IEEE,
+// (Y800, NV12 and HSV are output flavours of the fused kernels, vpp_kernels.hip.)  One launch per batch
+// of <= 64 frames (pointer table in the kernarg segment), thread = two horizontal pixel pairs.  Same arithmetic contract as vpp_kernels.hip: plain IEEE,
 // no contraction; integer paths use C integer semantics exactly as the reference's <uchar> code.
 #include "vpp_kernels.h"
 
@@ -31,171 +29,228 @@ __device__ __forceinline__ int chroma_422(const Nv12View &s, int i, int col) {
     return v;
 }
 
-template <class T> __device__ __forceinline__ T fin(int v, bool norm);
-template <> __device__ __forceinline__ uint8_t fin<uint8_t>(int v, bool norm) { return norm ? (uint8_t)((uint8_t)v / 255) : (uint8_t)v; }
-template <> __device__ __forceinline__ float fin<float>(int v, bool norm) { return norm ? (float)v / 255.0f : (float)v; }
-
-template <class T>
-__global__ __launch_bounds__(256) void fmt_y800(Nv12View s, T *out, bool norm) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= s.w) return;
-    out[(size_t)i * s.w + j] = fin<T>(s.y[(size_t)i * s.py + j], norm);
+// uint8 outputs are the raw values, fp32 outputs are normalised (the C ABI ties fp32 to normalization)
+// The same for the four bytes (U0 V0 U1 V1) at byte columns col .. col + 3 of the UV plane, one load per
+// tap row; A4: the plane base, the pitch and col are multiples of 4 (dword loads).
+template <bool A4> __device__ __forceinline__ uint32_t ld4(const uint8_t *p) {
+    if constexpr (A4) return *(const uint32_t *)p;
+    else return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+template <bool A4> __device__ __forceinline__ void chroma_422x4(const Nv12View &s, int i, int col, int v[4]) {
+    const int row = i >> 1, last = (s.h >> 1) - 1;
+    const uint32_t a = ld4<A4>(s.uv + (size_t)row * s.puv + col);
+    if (row & 1) { // uniform per wave: a wave serves one output row
+        const uint32_t b = ld4<A4>(s.uv + (size_t)min(row + 1, last) * s.puv + col);
+        const uint32_t c = ld4<A4>(s.uv + (size_t)max(row - 1, 0) * s.puv + col);
+        const uint32_t e = ld4<A4>(s.uv + (size_t)min(row + 2, last) * s.puv + col);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int in = (int)((a >> (8 * k)) & 255) + (int)((b >> (8 * k)) & 255);
+            const int out = (int)((c >> (8 * k)) & 255) + (int)((e >> (8 * k)) & 255);
+            v[k] = min(max((9 * in - out + 8) >> 4, 0), 255);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (int)((a >> (8 * k)) & 255);
+    }
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void fmt_nv12(Nv12View s, T *out, bool norm) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= s.w) return;
-    out[(size_t)i * s.w + j] = fin<T>(s.y[(size_t)i * s.py + j], norm);
-    if ((i & 1) == 0) out[(size_t)s.w * s.h + (size_t)(i >> 1) * s.w + j] = fin<T>(s.uv[(size_t)(i >> 1) * s.puv + j], norm);
+template <class T> __device__ __forceinline__ T fin(int v);
+template <> __device__ __forceinline__ uint8_t fin<uint8_t>(int v) { return (uint8_t)v; }
+template <> __device__ __forceinline__ float fin<float>(int v) { return (float)v / 255.0f; }
+
+struct FmtGeom {
+    int py, puv, w, h;
+    int aligned4; // every plane pointer and both pitches are multiples of 4
+};
+constexpr int FMT_BX = 64, FMT_BY = 4; // workgroup = 64 x 4 threads, thread = PAIRS horizontal pixel pairs
+
+// UYVY: thread = PAIRS pixel pairs of row i (w is even: a pair never straddles rows); PAIRS == 2 needs
+// w % 4 == 0 and 16-byte aligned outputs (one 8-byte / two 16-byte stores per thread)
+template <class T, int PAIRS>
+__global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_uyvy(const FrameTable t, const FmtGeom g) {
+    const int f = blockIdx.z, i = blockIdx.y * FMT_BY + threadIdx.y, j = (blockIdx.x * FMT_BX + threadIdx.x) * 2 * PAIRS;
+    if (i >= g.h || j >= g.w) return;
+    const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
+    int v[4 * PAIRS];
+    if constexpr (PAIRS == 2) { // j % 4 == 0: one load per luma / chroma row
+        int c[4];
+        uint32_t yw;
+        if (g.aligned4) {
+            chroma_422x4<true>(s, i, j, c);
+            yw = ld4<true>(s.y + (size_t)i * s.py + j);
+        } else {
+            chroma_422x4<false>(s, i, j, c);
+            yw = ld4<false>(s.y + (size_t)i * s.py + j);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            v[4 * p] = c[2 * p];
+            v[4 * p + 1] = (int)((yw >> (16 * p)) & 255);
+            v[4 * p + 2] = c[2 * p + 1];
+            v[4 * p + 3] = (int)((yw >> (16 * p + 8)) & 255);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < PAIRS; p++) {
+            v[4 * p] = chroma_422(s, i, j + 2 * p);
+            v[4 * p + 1] = s.y[(size_t)i * s.py + j + 2 * p];
+            v[4 * p + 2] = chroma_422(s, i, j + 2 * p + 1);
+            v[4 * p + 3] = s.y[(size_t)i * s.py + j + 2 * p + 1];
+        }
+    }
+    T *o = (T *)t.out[f] + ((size_t)i * s.w + j) * 2;
+    if constexpr (PAIRS == 2 && sizeof(T) == 1) {
+        uint2 w;
+        w.x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        w.y = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+        __builtin_nontemporal_store(w.x, (uint32_t *)o);
+        __builtin_nontemporal_store(w.y, (uint32_t *)o + 1);
+    } else if constexpr (PAIRS == 2) {
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const vf4 a = { fin<float>(v[0]), fin<float>(v[1]), fin<float>(v[2]), fin<float>(v[3]) };
+        const vf4 b = { fin<float>(v[4]), fin<float>(v[5]), fin<float>(v[6]), fin<float>(v[7]) };
+        __builtin_nontemporal_store(a, (vf4 *)o);
+        __builtin_nontemporal_store(b, (vf4 *)o + 1);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) o[c] = fin<T>(v[c]);
+    }
 }
 
-// thread = pixel pair (2q, 2q+1) in flat order (w is even: a pair never straddles rows)
-template <class T>
-__global__ __launch_bounds__(256) void fmt_uyvy(Nv12View s, T *out, bool norm) {
-    const int jp = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (2 * jp >= s.w) return;
-    const int j = 2 * jp;
-    T *o = out + ((size_t)i * s.w + j) * 2;
-    o[0] = fin<T>(chroma_422(s, i, j), norm);
-    o[1] = fin<T>(s.y[(size_t)i * s.py + j], norm);
-    o[2] = fin<T>(chroma_422(s, i, j + 1), norm);
-    o[3] = fin<T>(s.y[(size_t)i * s.py + j + 1], norm);
-}
-
-// U (comp 0) / V (comp 1) of flat pixel pair q of the intermediate UYVY image; pairs past the end
-// read as 0 (the reference reads past its buffer there, src/ColorConversion.cu:131-138).
-__device__ __forceinline__ int uyvy_chroma(const Nv12View &s, long q, int comp) {
-    const long npairs = (long)s.w * s.h / 2;
-    if (q < 0 || q >= npairs) return 0;
-    const long idx = 2 * q;
-    const int i = (int)(idx / s.w), j = (int)(idx - (long)i * s.w);
+// U (comp 0) / V (comp 1) of the pixel pair at (row i, even column j) of the intermediate UYVY image,
+// where j may run off either end of the row: the reference indexes that image FLAT, so the pair before
+// the first of a row is the last of the previous row; pairs before the image or past its end read as 0
+// (the reference reads outside its buffer there, src/ColorConversion.cu:131-138).
+__device__ __forceinline__ int uyvy_chroma(const Nv12View &s, int i, int j, int comp) {
+    while (j < 0) {
+        j += s.w;
+        i--;
+    }
+    while (j >= s.w) {
+        j -= s.w;
+        i++;
+    }
+    if (i < 0 || i >= s.h) return 0;
     return chroma_422(s, i, j + comp);
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void fmt_yuv444(Nv12View s, T *out, bool norm) {
-    const int jp = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (2 * jp >= s.w) return;
+template <class T> __device__ __forceinline__ T yuv444_odd(int p1, int p2, int p3, int p4) {
+    if constexpr (sizeof(T) == 1) {
+        return (T)(uint8_t)((9 * (p1 + p2) - (p3 + p4) + 8) / 16); // C division, then wrap to uchar
+    } else {
+        float a = (float)p1 + (float)p2;
+        a = 9.0f * a;
+        const float b = (float)p3 + (float)p4;
+        float v = a - b;
+        v = v + 8.0f;
+        v = v / 16.0f;
+        v = fminf(v, 255.0f);
+        v = fmaxf(v, 0.0f);
+        return (T)(v / 255.0f);
+    }
+}
+
+// YUV444 planar: even pixels take their pair's chroma, odd pixels (9 (p1 + p2) - (p3 + p4) + 8) / 16 over the
+// neighbouring pairs in FLAT order.  Thread = PAIRS pairs; the chroma of pairs -1 .. PAIRS + 1 is computed once.
+template <class T, int PAIRS>
+__global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444(const FrameTable t, const FmtGeom g) {
+    const int f = blockIdx.z, i = blockIdx.y * FMT_BY + threadIdx.y, j = (blockIdx.x * FMT_BX + threadIdx.x) * 2 * PAIRS;
+    if (i >= g.h || j >= g.w) return;
+    const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
     const size_t wh = (size_t)s.w * s.h;
-    const long idx0 = (long)i * s.w + 2 * jp, q = idx0 >> 1, npairs = (long)(wh / 2);
-    // even pixel: its own pair's chroma
-    const int u0 = uyvy_chroma(s, q, 0), v0 = uyvy_chroma(s, q, 1);
-    out[idx0] = fin<T>(s.y[(size_t)i * s.py + 2 * jp], norm);
-    out[wh + idx0] = fin<T>(u0, norm);
-    out[2 * wh + idx0] = fin<T>(v0, norm);
-    // odd pixel: (9 (p1 + p2) - (p3 + p4) + 8) / 16 over the neighbouring pairs in FLAT order
-    const long idx1 = idx0 + 1, src = 2 * idx1 + 1;
-    out[idx1] = fin<T>(s.y[(size_t)i * s.py + 2 * jp + 1], norm);
+    int c[PAIRS + 3][2]; // chroma of pairs -1 .. PAIRS + 1 relative to this thread's first
+    bool fast = false;
+    if constexpr (PAIRS == 2) fast = (j >= 4) && (j + 8 <= s.w);
+    if (fast) { // all five pairs lie in row i: bytes j - 2 .. j + 7 of the chroma row(s), three loads per tap row
+        if constexpr (PAIRS == 2) {
+            int l[4], m[4], r[4];
+            if (g.aligned4) {
+                chroma_422x4<true>(s, i, j - 4, l);
+                chroma_422x4<true>(s, i, j, m);
+                chroma_422x4<true>(s, i, j + 4, r);
+            } else {
+                chroma_422x4<false>(s, i, j - 4, l);
+                chroma_422x4<false>(s, i, j, m);
+                chroma_422x4<false>(s, i, j + 4, r);
+            }
+            c[0][0] = l[2], c[0][1] = l[3];
+            c[1][0] = m[0], c[1][1] = m[1];
+            c[2][0] = m[2], c[2][1] = m[3];
+            c[3][0] = r[0], c[3][1] = r[1];
+            c[4][0] = r[2], c[4][1] = r[3];
+        }
+    } else {
 #pragma unroll
-    for (int comp = 0; comp < 2; comp++) {
-        const int shift = 2 * comp;
-        const int p1 = comp ? v0 : u0;
-        const int p2 = uyvy_chroma(s, q + 1, comp);
-        const int p3 = (src - 7 + shift < 0) ? p1 : uyvy_chroma(s, q - 1, comp);
-        const int p4 = (src + 5 + shift > (long)(2 * wh) - 1) ? p2 : uyvy_chroma(s, q + 2, comp);
-        (void)npairs;
-        if constexpr (sizeof(T) == 1) {
-            uint8_t v = (uint8_t)((9 * (p1 + p2) - (p3 + p4) + 8) / 16); // C division, then wrap to uchar
-            if (norm) v = (uint8_t)(v / 255);
-            out[(1 + comp) * wh + idx1] = (T)v;
-        } else {
-            float a = (float)p1 + (float)p2;
-            a = 9.0f * a;
-            const float b = (float)p3 + (float)p4;
-            float v = a - b;
-            v = v + 8.0f;
-            v = v / 16.0f;
-            v = fminf(v, 255.0f);
-            v = fmaxf(v, 0.0f);
-            if (norm) v = v / 255.0f;
-            out[(1 + comp) * wh + idx1] = (T)v;
+        for (int k = 0; k < PAIRS + 3; k++) {
+            c[k][0] = uyvy_chroma(s, i, j + 2 * (k - 1), 0);
+            c[k][1] = uyvy_chroma(s, i, j + 2 * (k - 1), 1);
+        }
+    }
+    T yv[2 * PAIRS], uo[2 * PAIRS], vo[2 * PAIRS];
+    if constexpr (PAIRS == 2) {
+        const uint32_t yw = g.aligned4 ? ld4<true>(s.y + (size_t)i * s.py + j) : ld4<false>(s.y + (size_t)i * s.py + j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) yv[q] = fin<T>((int)((yw >> (8 * q)) & 255));
+    } else {
+        yv[0] = fin<T>(s.y[(size_t)i * s.py + j]);
+        yv[1] = fin<T>(s.y[(size_t)i * s.py + j + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < PAIRS; p++) {
+        const long idx0 = (long)i * s.w + j + 2 * p, idx1 = idx0 + 1, src = 2 * idx1 + 1;
+        uo[2 * p] = fin<T>(c[p + 1][0]);
+        vo[2 * p] = fin<T>(c[p + 1][1]);
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            const int shift = 2 * comp;
+            const int p1 = c[p + 1][comp], p2 = c[p + 2][comp];
+            const int p3 = (src - 7 + shift < 0) ? p1 : c[p][comp];
+            const int p4 = (src + 5 + shift > (long)(2 * wh) - 1) ? p2 : c[p + 3][comp];
+            (comp ? vo : uo)[2 * p + 1] = yuv444_odd<T>(p1, p2, p3, p4);
+        }
+    }
+    T *o = (T *)t.out[f] + (size_t)i * s.w + j;
+    if constexpr (PAIRS == 2 && sizeof(T) == 1) {
+        auto pk = [](const T *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+        __builtin_nontemporal_store(pk(yv), (uint32_t *)o);
+        __builtin_nontemporal_store(pk(uo), (uint32_t *)(o + wh));
+        __builtin_nontemporal_store(pk(vo), (uint32_t *)(o + 2 * wh));
+    } else if constexpr (PAIRS == 2) {
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((vf4){ yv[0], yv[1], yv[2], yv[3] }, (vf4 *)o);
+        __builtin_nontemporal_store((vf4){ uo[0], uo[1], uo[2], uo[3] }, (vf4 *)(o + wh));
+        __builtin_nontemporal_store((vf4){ vo[0], vo[1], vo[2], vo[3] }, (vf4 *)(o + 2 * wh));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            o[q] = yv[q];
+            o[wh + q] = uo[q];
+            o[2 * wh + q] = vo[q];
         }
     }
 }
 
-__device__ __forceinline__ int clamp_byte(int v) { return max(min(v, 255), 0); }
-
-// NV12 -> normalised RGB (src/ColorConversion.cu:6-39, 68-93 with normalization) -> HSV (:235-278)
-__global__ __launch_bounds__(256) void fmt_hsv(Nv12View s, float *out, tsvpp_coeffs k) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= s.w) return;
-    const int Y = s.y[(size_t)i * s.py + j];
-    const int U = s.uv[(size_t)(i >> 1) * s.puv + (j & ~1)], V = s.uv[(size_t)(i >> 1) * s.puv + (j & ~1) + 1];
-    const float yv = fmaxf(0.0f, (float)Y - k.y_offset) * k.y_scale;
-    const float fu = (float)U - k.c_offset, fv = (float)V - k.c_offset;
-    float rv = k.v_to_r * fv;
-    rv = rv + k.round_bias;
-    float bv = k.u_to_b * fu;
-    bv = bv + k.round_bias;
-    const float g1 = k.v_to_g * fv, g2 = k.u_to_g * fu;
-    float gv = g1 + g2;
-    gv = gv + k.round_bias;
-    const float R = (float)clamp_byte((int)(yv + rv)) / 255.0f;
-    const float G = (float)clamp_byte((int)(yv + gv)) / 255.0f;
-    const float B = (float)clamp_byte((int)(yv + bv)) / 255.0f;
-    const float mn = fminf(fminf(R, G), B), mx = fmaxf(fmaxf(R, G), B);
-    const float delta = mx - mn;
-    float *o = out + ((size_t)i * s.w + j) * 3;
-    o[2] = mx;
-    float S = 0.0f;
-    if (mx != 0.0f) {
-        const float q = mn / mx;
-        S = 1.0f - q;
-    }
-    o[1] = S;
-    if (mx == mn) {
-        o[0] = 0.0f;
-        return;
-    }
-    float H = 0.0f;
-    if (R == mx && G >= B) {
-        H = 60.0f * (G - B);
-        H = H / delta;
-    } else if (R == mx && G < B) {
-        H = 60.0f * (G - B);
-        H = H / delta;
-        H = H + 360.0f;
-    } else if (G == mx) {
-        H = 60.0f * (B - R);
-        H = H / delta;
-        H = H + 120.0f;
-    } else if (B == mx) {
-        H = 60.0f * (R - G);
-        H = H / delta;
-        H = H + 240.0f;
-    }
-    if (H < 0.0f) H = H + 360.0f;
-    H = H / 360.0f;
-    o[0] = H;
-}
-
-hipError_t launch_format(int fourcc, bool f32, bool norm, const uint8_t *y, const uint8_t *uv, int py, int puv, int w, int h, void *out,
-                         const tsvpp_coeffs &k, hipStream_t stream) {
-    Nv12View s{ y, uv, py, puv, w, h };
-    const dim3 block(256), gpix((w + 255) / 256, h), gpair((w / 2 + 255) / 256, h);
+hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int py, int puv, int w, int h, hipStream_t stream) {
+    bool wide = (w % 4) == 0, a4 = (py % 4) == 0 && (puv % 4) == 0;
+    for (int f = 0; f < n && wide; f++) wide = ((uintptr_t)t.out[f] & 15) == 0;
+    for (int f = 0; f < n && a4; f++) a4 = (((uintptr_t)t.y[f] | (uintptr_t)t.uv[f]) & 3) == 0;
+    const FmtGeom g{ py, puv, w, h, a4 ? 1 : 0 };
+    const int pairs = wide ? 2 : 1;
+    const dim3 block(FMT_BX, FMT_BY), grid((w / (2 * pairs) + FMT_BX - 1) / FMT_BX, (h + FMT_BY - 1) / FMT_BY, n);
+#define TSVPP_FMT(K)                                                                                      \
+    do {                                                                                                  \
+        if (f32 && wide) hipLaunchKernelGGL((K<float, 2>), grid, block, 0, stream, t, g);                 \
+        else if (f32) hipLaunchKernelGGL((K<float, 1>), grid, block, 0, stream, t, g);                    \
+        else if (wide) hipLaunchKernelGGL((K<uint8_t, 2>), grid, block, 0, stream, t, g);                 \
+        else hipLaunchKernelGGL((K<uint8_t, 1>), grid, block, 0, stream, t, g);                           \
+    } while (0)
     switch (fourcc) {
-    case TSVPP_Y800:
-        if (f32) hipLaunchKernelGGL(fmt_y800<float>, gpix, block, 0, stream, s, (float *)out, norm);
-        else hipLaunchKernelGGL(fmt_y800<uint8_t>, gpix, block, 0, stream, s, (uint8_t *)out, norm);
-        break;
-    case TSVPP_NV12:
-        if (f32) hipLaunchKernelGGL(fmt_nv12<float>, gpix, block, 0, stream, s, (float *)out, norm);
-        else hipLaunchKernelGGL(fmt_nv12<uint8_t>, gpix, block, 0, stream, s, (uint8_t *)out, norm);
-        break;
-    case TSVPP_UYVY:
-        if (f32) hipLaunchKernelGGL(fmt_uyvy<float>, gpair, block, 0, stream, s, (float *)out, norm);
-        else hipLaunchKernelGGL(fmt_uyvy<uint8_t>, gpair, block, 0, stream, s, (uint8_t *)out, norm);
-        break;
-    case TSVPP_YUV444:
-        if (f32) hipLaunchKernelGGL(fmt_yuv444<float>, gpair, block, 0, stream, s, (float *)out, norm);
-        else hipLaunchKernelGGL(fmt_yuv444<uint8_t>, gpair, block, 0, stream, s, (uint8_t *)out, norm);
-        break;
-    case TSVPP_HSV:
-        hipLaunchKernelGGL(fmt_hsv, gpix, block, 0, stream, s, (float *)out, k);
-        break;
+    case TSVPP_UYVY: TSVPP_FMT(fmt_uyvy); break;
+    case TSVPP_YUV444: TSVPP_FMT(fmt_yuv444); break;
     default: return hipErrorInvalidValue;
     }
+#undef TSVPP_FMT
     return hipGetLastError();
 }
 

@@ -70,20 +70,23 @@ struct LaunchDesc {
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)
+    int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
 };
 
 // Output flavour: element type x layout.
-// O_NV12_U8: the resized NV12 itself (Y plane then interleaved UV plane, tight) -- the intermediate the
-// reference hands to its other colour kernels; feeds vpp_formats.hip.
-enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_COUNT };
+// O_NV12_*: the resized NV12 itself (Y plane then interleaved UV plane, tight) -- FourCC NV12 of the
+// reference (NV12MergeBuffers, src/ColorConversion.cu:211-233), and as uint8 also the intermediate
+// the two-pass formats (UYVY, YUV444; vpp_formats.hip) read.  O_Y800_*: the luma plane alone
+// (:95-105).  O_HSV_F32: merged HSV of the normalised RGB (:235-278).  The fp32 flavours are /255.
+enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_NV12_F32, O_Y800_U8, O_Y800_F32, O_HSV_F32, O_COUNT };
 
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
 // store path (needs dst_w % 4 == 0 and 16-byte aligned outputs).  Returns hipError_t.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream);
 
-// Y800 / NV12 / UYVY / YUV444 / HSV from one NV12 frame (vpp_formats.hip).
-hipError_t launch_format(int fourcc, bool f32, bool norm, const uint8_t *y, const uint8_t *uv, int py, int puv, int w, int h, void *out,
-                         const tsvpp_coeffs &k, hipStream_t stream);
+// UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);
+// t.y / t.uv are the (resized or cropped) NV12 planes, t.out the outputs.
+hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int py, int puv, int w, int h, hipStream_t stream);
 
 } // namespace tsvpp

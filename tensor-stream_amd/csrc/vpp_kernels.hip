@@ -312,6 +312,10 @@ __device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, i
 template <int OUT> struct OutT { using type = uint8_t; };
 template <> struct OutT<O_F32_PLANAR> { using type = float; };
 template <> struct OutT<O_F32_MERGED> { using type = float; };
+template <> struct OutT<O_NV12_F32> { using type = float; };
+template <> struct OutT<O_Y800_F32> { using type = float; };
+template <> struct OutT<O_HSV_F32> { using type = float; };
+template <int OUT> constexpr bool kLumaOnly = (OUT == O_Y800_U8 || OUT == O_Y800_F32);
 
 // Per-block chroma terms: t0 / t2 are added to luma for the first / third stored channel
 // (R,B or B,R when swapped), tg for green.
@@ -347,6 +351,26 @@ __device__ __forceinline__ f2 norm255(f2 v) {
     return q;
 }
 
+// Normalised RGB -> HSV in [0, 1], the reference's RGBMergedToHSVMerged (src/ColorConversion.cu:235-278),
+// branch-free: the hue sector is chosen with selects, every operation keeps its place and its IEEE
+// rounding (`/` is the correctly rounded division).
+__device__ __forceinline__ void hsv_pixel(float R, float G, float B, float &H, float &S, float &V) {
+    const float mn = __builtin_fminf(__builtin_fminf(R, G), B), mx = __builtin_fmaxf(__builtin_fmaxf(R, G), B);
+    const float delta = mx - mn;
+    V = mx;
+    const float q = mn / mx;
+    S = (mx != 0.0f) ? 1.0f - q : 0.0f;
+    const bool r = (R == mx), g = (G == mx);
+    const float diff = r ? G - B : (g ? B - R : R - G);
+    const float off = r ? (G < B ? 360.0f : 0.0f) : (g ? 120.0f : 240.0f);
+    float h = 60.0f * diff;
+    h = h / delta;
+    h = h + off;
+    if (h < 0.0f) h = h + 360.0f;
+    h = h / 360.0f;
+    H = (mx == mn) ? 0.0f : h;
+}
+
 typedef float vf4 __attribute__((ext_vector_type(4)));
 // Output store policy (LaunchDesc::nt_stores): 0 plain, 1 non-temporal, 2 `sc1` write-through.  The
 // output is written once and never re-read by the kernel, so it should not displace the input
@@ -372,10 +396,33 @@ __device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, in
     else *(uint32_t *)(base + off) = v;
 }
 
+// Merged fp32 outputs (RGB / HSV triples): a thread owns 48 contiguous bytes of an output row, so its three
+// 16-byte stores would interleave with its neighbours' at a 48-byte stride -- every store instruction
+// touches every 128-byte line of the row segment without completing one.  Instead the A active lanes of a
+// "run" (the lanes of one wave that share an output row: min(tx, 64)) swap data through a per-wave LDS slab
+// and store instruction k writes bytes [16 A k, 16 A (k + 1)) of the run's 48 A contiguous bytes.  Only
+// lanes of one wave exchange data and LDS operations of a wave execute in order: no barrier.
+struct MergedRun {
+    uint8_t *lds; // the run's slab
+    int m, a;     // lane index within the run, active lanes of the run (right edge: fewer than the run length)
+};
+template <int OUT, bool VEC> __device__ __forceinline__ MergedRun merged_run(const LaunchDesc &d, int j0) {
+    MergedRun r{ nullptr, 0, 1 };
+    if constexpr (VEC && (OUT == O_F32_MERGED || OUT == O_HSV_F32)) {
+        __shared__ __attribute__((aligned(16))) uint8_t slab[MAX_THREADS * 48];
+        const int len = min(d.tx, 64);
+        r.m = threadIdx.x & (len - 1);
+        r.a = min(len, (d.dst_w - (j0 - PXW * r.m)) / PXW);
+        r.lds = slab + ((int)threadIdx.x - r.m) * 48;
+    }
+    return r;
+}
+
 // One output row of this thread: 4 pixels -> 3 channels, converted and stored.
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float t0[2], const float tg[2], const float t2[2],
-                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, uint32_t pix, uint32_t plane, int ncol, int nt) {
+                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, uint32_t pix, uint32_t plane, int ncol, int nt,
+                                                const MergedRun &run) {
     using T = typename OutT<OUT>::type;
     constexpr bool PLANAR = (OUT == O_U8_PLANAR || OUT == O_F32_PLANAR);
     f2 c0[2], c1[2], c2[2]; // channel values of pixel pairs (0,1) and (2,3)
@@ -397,6 +444,17 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
             c1[p] = norm255(c1[p]);
             c2[p] = norm255(c2[p]);
         }
+        if constexpr (OUT == O_HSV_F32) { // (c0, c1, c2) = normalised (R, G, B) -> merged (H, S, V)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                float h[2], sa[2], v[2];
+                hsv_pixel(c0[p].x, c1[p].x, c2[p].x, h[0], sa[0], v[0]);
+                hsv_pixel(c0[p].y, c1[p].y, c2[p].y, h[1], sa[1], v[1]);
+                c0[p] = (f2){ h[0], h[1] };
+                c1[p] = (f2){ sa[0], sa[1] };
+                c2[p] = (f2){ v[0], v[1] };
+            }
+        }
         float *o = (float *)out;
         if constexpr (VEC) {
             if constexpr (PLANAR) {
@@ -407,10 +465,21 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                 st4o(b1, boff, c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
                 st4o(b2, boff, c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
             } else {
-                const uint32_t q = pix * 12u;
-                st4o((uint8_t *)o, q, c0[0].x, c1[0].x, c2[0].x, c0[0].y, nt);
-                st4o((uint8_t *)o, q + 16u, c1[0].y, c2[0].y, c0[1].x, c1[1].x, nt);
-                st4o((uint8_t *)o, q + 32u, c2[1].x, c0[1].y, c1[1].y, c2[1].y, nt);
+                // merged: the lanes of a run exchange their 48-byte pixel quads through LDS so that each
+                // store instruction of the run writes one contiguous 16 * A byte span (see MergedRun)
+                uint8_t *w = run.lds;
+                *(vf4 *)(w + 48 * run.m) = (vf4){ c0[0].x, c1[0].x, c2[0].x, c0[0].y };
+                *(vf4 *)(w + 48 * run.m + 16) = (vf4){ c1[0].y, c2[0].y, c0[1].x, c1[1].x };
+                *(vf4 *)(w + 48 * run.m + 32) = (vf4){ c2[1].x, c0[1].y, c1[1].y, c2[1].y };
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t q = (pix - 4u * (uint32_t)run.m) * 12u; // first byte of the run in this row
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    const uint32_t off = (uint32_t)(kk * run.a + run.m) * 16u;
+                    const vf4 v = *(const vf4 *)(w + off);
+                    st4o((uint8_t *)o, q + off, v.x, v.y, v.z, v.w, nt);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
             const float v0[4] = { c0[0].x, c0[0].y, c0[1].x, c0[1].y }, v1[4] = { c1[0].x, c1[0].y, c1[1].x, c1[1].y },
@@ -463,24 +532,59 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
                                                  typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
-    if constexpr (OUT == O_NV12_U8) { // no colour conversion: the resized NV12 intermediate itself
-        uint8_t *o = (uint8_t *)out;
+    if constexpr (OUT == O_NV12_U8 || OUT == O_NV12_F32 || OUT == O_Y800_U8 || OUT == O_Y800_F32) {
+        // no colour conversion: the resized samples themselves (fp32: / 255), Y plane then UV plane
+        using T = typename OutT<OUT>::type;
+        constexpr bool CHROMA = (OUT == O_NV12_U8 || OUT == O_NV12_F32);
+        const int nt = d.nt_stores;
         const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
-#pragma unroll
-        for (int r = 0; r < PXH; r++) {
-            const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
-            if constexpr (VEC) *(uchar4 *)(o + pix) = make_uchar4((uint8_t)Yf[r][0], (uint8_t)Yf[r][1], (uint8_t)Yf[r][2], (uint8_t)Yf[r][3]);
-            else
-                for (int c = 0; c < ncol; c++) o[pix + c] = (uint8_t)Yf[r][c];
-        }
         const uint32_t cpix = plane + (uint32_t)(i0 >> 1) * (uint32_t)d.dst_w + (uint32_t)j0;
-        if constexpr (VEC) *(uchar4 *)(o + cpix) = make_uchar4((uint8_t)Uf[0], (uint8_t)Vf[0], (uint8_t)Uf[1], (uint8_t)Vf[1]);
-        else {
-            o[cpix] = (uint8_t)Uf[0];
-            o[cpix + 1] = (uint8_t)Vf[0];
-            if (ncol > 2) {
-                o[cpix + 2] = (uint8_t)Uf[1];
-                o[cpix + 3] = (uint8_t)Vf[1];
+        if constexpr (sizeof(T) == 1) {
+            uint8_t *o = (uint8_t *)out;
+            auto pk = [](float a, float b, float c, float e) {
+                return (uint32_t)(int)a | ((uint32_t)(int)b << 8) | ((uint32_t)(int)c << 16) | ((uint32_t)(int)e << 24);
+            };
+#pragma unroll
+            for (int r = 0; r < PXH; r++) {
+                const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+                if constexpr (VEC) st1o(o, pix, pk(Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3]), nt);
+                else
+                    for (int c = 0; c < ncol; c++) o[pix + c] = (uint8_t)Yf[r][c];
+            }
+            if constexpr (CHROMA) {
+                if constexpr (VEC) st1o(o, cpix, pk(Uf[0], Vf[0], Uf[1], Vf[1]), nt);
+                else {
+                    o[cpix] = (uint8_t)Uf[0];
+                    o[cpix + 1] = (uint8_t)Vf[0];
+                    if (ncol > 2) {
+                        o[cpix + 2] = (uint8_t)Uf[1];
+                        o[cpix + 3] = (uint8_t)Vf[1];
+                    }
+                }
+            }
+        } else {
+            float *o = (float *)out;
+#pragma unroll
+            for (int r = 0; r < PXH; r++) {
+                const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+                const f2 a = norm255((f2){ Yf[r][0], Yf[r][1] }), b = norm255((f2){ Yf[r][2], Yf[r][3] });
+                if constexpr (VEC) st4o((uint8_t *)o, pix * 4u, a.x, a.y, b.x, b.y, nt);
+                else {
+                    const float v[4] = { a.x, a.y, b.x, b.y };
+                    for (int c = 0; c < ncol; c++) o[pix + c] = v[c];
+                }
+            }
+            if constexpr (CHROMA) {
+                const f2 a = norm255((f2){ Uf[0], Vf[0] }), b = norm255((f2){ Uf[1], Vf[1] });
+                if constexpr (VEC) st4o((uint8_t *)o, cpix * 4u, a.x, a.y, b.x, b.y, nt);
+                else {
+                    o[cpix] = a.x;
+                    o[cpix + 1] = a.y;
+                    if (ncol > 2) {
+                        o[cpix + 2] = b.x;
+                        o[cpix + 3] = b.y;
+                    }
+                }
             }
         }
         return;
@@ -492,9 +596,10 @@ __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const
     // SGPR-base + VGPR-offset addressing mode instead of per-lane 64-bit pointer arithmetic
     // (host side guarantees 3 * W * H * sizeof(T) < 4 GiB)
     const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+    const MergedRun run = merged_run<OUT, VEC>(d, j0);
 #pragma unroll
     for (int r = 0; r < PXH; r++)
-        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0, plane, ncol, d.nt_stores);
+        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0, plane, ncol, d.nt_stores, run);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -540,7 +645,8 @@ __device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         int U = 128, V = 128;
-        if (VEC || 2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
+        if constexpr (!kLumaOnly<OUT>)
+            if (VEC || 2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
         Uf[c] = (float)U;
         Vf[c] = (float)V;
     }
@@ -744,7 +850,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const Lau
     const uint8_t *ay, *auv;
     s.py_ = describe_plane(lds_raw, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     s.puv_ = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
         stage_plane_dma(lds_raw, ay, s.py_, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
@@ -892,7 +998,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const uint8_t *ay, *auv;
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
 #ifdef TSVPP_ABLATION
     if (!(d.ablate & 2))
 #endif
@@ -990,7 +1096,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_kernel(const LaunchDe
     const uint8_t *ay, *auv;
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
         stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
@@ -1145,7 +1251,7 @@ __device__ __forceinline__ void tile_ctx(const LaunchDesc &d, const FrameTable &
     c.py = describe_plane(lds_y, t.y[c.id.frame], d.pitch_y, c.f.ylo, c.f.xlo, d.lds_cpr_y, c.ay);
     c.puv = describe_plane(lds_uv, t.uv[c.id.frame], d.pitch_uv, c.f.cylo, 2 * c.f.cxlo, d.lds_cpr_uv, c.auv);
     c.ny = min(c.f.yhi - c.f.ylo + 1, d.lds_rows_y);
-    c.nuv = min(c.f.cyhi - c.f.cylo + 1, d.lds_rows_uv);
+    c.nuv = d.luma_only ? 0 : min(c.f.cyhi - c.f.cylo + 1, d.lds_rows_uv);
     c.span_y = min(c.f.xhi - c.f.xlo + 1, d.lds_span_y);
     c.span_uv = min(2 * (c.f.cxhi - c.f.cxlo + 1), d.lds_span_uv);
 }
@@ -1282,7 +1388,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     const uint8_t *ay, *auv;
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     // small workgroups (large footprints) must keep many chunks per lane in flight, or the staging
     // is latency-bound: LDS-DMA issues them all without holding registers; the register path keeps
     // 16 + 8 chunks per lane for 64 threads, 4 + 2 for 256
@@ -1673,7 +1779,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_point_kernel(const LaunchDesc
     const int cxlo = min(max(point_coord<KIND>(j_first >> 1, d.xr, d.src_w), 0), cw - 1);
     const int cxhi = min(max(point_coord<KIND>(j_last >> 1, d.xr, d.src_w), 0), cw - 1);
     const int span_y = min(xhi - xlo + 1, d.lds_span_y), span_uv = min(2 * (cxhi - cxlo + 1), d.lds_span_uv);
-    const int ny = i_last - i_first + 1, nuv = (i_last >> 1) - (i_first >> 1) + 1;
+    const int ny = i_last - i_first + 1, nuv = d.luma_only ? 0 : (i_last >> 1) - (i_first >> 1) + 1;
 
     uint8_t *lds_y = lds_raw;
     uint8_t *lds_uv = lds_raw + th * d.lds_cpr_y * 16;
@@ -1865,6 +1971,10 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
     case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, staged, d, t, lds, stream);
     case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, staged, d, t, lds, stream);
     case O_NV12_U8: return launch_mo<MODE, O_NV12_U8>(vec, staged, d, t, lds, stream);
+    case O_NV12_F32: return launch_mo<MODE, O_NV12_F32>(vec, staged, d, t, lds, stream);
+    case O_Y800_U8: return launch_mo<MODE, O_Y800_U8>(vec, staged, d, t, lds, stream);
+    case O_Y800_F32: return launch_mo<MODE, O_Y800_F32>(vec, staged, d, t, lds, stream);
+    case O_HSV_F32: return launch_mo<MODE, O_HSV_F32>(vec, staged, d, t, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1872,9 +1982,14 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream) {
     LaunchDesc d = din;
     d.rpt = 1;
+    d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
     if (d.nt_stores < 0) { // per-kernel default
-        const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED);
-        d.nt_stores = (mode == M_NONE && f32) ? 2 : 1;
+        // fp32 outputs: every store instruction of a wave covers whole 128-byte lines (planar: 16 contiguous
+        // bytes per lane; merged: after the in-wave exchange of MergedRun) and nothing re-reads them.  The
+        // scalar fallback of merged outputs (!vec) interleaves partial lines: plain stores, L2 combines them.
+        const bool f32_lines = (out == O_F32_PLANAR || out == O_NV12_F32 || out == O_Y800_F32) || (vec && (out == O_F32_MERGED || out == O_HSV_F32));
+        const bool f32_partial = !vec && (out == O_F32_MERGED || out == O_HSV_F32);
+        d.nt_stores = f32_partial ? 0 : ((mode == M_NONE && f32_lines) ? 2 : 1);
     }
     // Candidate workgroup shapes, largest first; the staged kernels take the first whose source
     // footprint fits the LDS budget (several workgroups per CU must stay resident to overlap one

@@ -108,3 +108,24 @@ def test_empty_batch_and_argument_errors(vpp):
     bad = (N.NV12 * 1)(N.NV12(y.data_ptr(), y.data_ptr(), 32, 32, 64, 36))                   # pitch < width
     outs = (ctypes.c_void_p * 1)(y.data_ptr())
     assert L.tsvpp_convert_batch(vpp._ctx, 1, bad, ctypes.byref(fp), outs, None) == -3
+
+
+@pytest.mark.parametrize("shape", [None, "16,4", "64,4", "128,2"])
+def test_merged_fp32_store_exchange(oracle, monkeypatch, shape):
+    """Merged fp32 outputs swap pixel quads between the lanes of a run before storing: every run length
+    (workgroup widths 16 / 32 / 64 / 128), ragged right edges (last run shorter than the others, down to one
+    lane), every kernel family, RGB triples and HSV."""
+    import tensor_stream as ts
+    if shape:
+        monkeypatch.setenv("TSVPP_SHAPE", shape)
+    v = ts.VideoProcessor(device=0, max_consumers=2)
+    try:
+        y, uv = synth_nv12(1080, 608, seed=4242, pitch=1088)
+        cases = [((0, 0), 0), ((132, 76), 0), ((300, 200), 1), ((1284, 724), 1), ((516, 290), 2), ((540, 304), 3), ((360, 152), 3),
+                 ((432, 244), 3), ((772, 436), 3), ((4, 2), 1), ((68, 40), 1)]
+        for dst, rt in cases:
+            for fourcc in (1, 6):
+                conv(v, oracle, y, uv, width=1080, dst=dst, rt=rt, planes=1, norm=True, fourcc=fourcc)
+        conv(v, oracle, y, uv, width=1080, crop=(121, 65, 601, 401), planes=1, norm=True, fourcc=1)
+    finally:
+        v.Close()

@@ -57,3 +57,45 @@ def test_batch_of_two_pass_format(vpp, oracle):
     for i in range(3):
         ref, _, _ = oracle.convert(frames[i][0], frames[i][1], dst=(320, 180), resize_type=1, fourcc=YUV444, normalization=True)
         assert np.array_equal(out[i].cpu().numpy().ravel().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("fcc", [Y800, NV12, HSV])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("dst,rt", [((540, 304), 0),      # NEAREST: point kernel
+                                    ((540, 304), 1),      # BILINEAR with zero weights: point kernel
+                                    ((1280, 720), 1),     # BILINEAR up: 2x2-tap kernel
+                                    ((720, 404), 2),      # BICUBIC: table kernel
+                                    ((540, 304), 3),      # AREA 2x: dyadic kernels
+                                    ((360, 152), 3),      # AREA 3x / 4x: direct dyadic kernel
+                                    ((432, 244), 3),      # AREA 2.5x / 2.49x: direct float kernel
+                                    ((1440, 808), 3),     # AREA up: bilinear variant
+                                    ((120, 76), 1)])      # BILINEAR 9x / 8x: sparse gather
+def test_fused_formats_every_kernel_family(vpp, oracle, fcc, norm, dst, rt):
+    """Y800 / NV12 / HSV are output flavours of the fused kernels: one case per kernel family."""
+    y, uv = synth_nv12(1080, 608, seed=fcc * 7 + rt + dst[0], pitch=1152)
+    got = run(vpp, y, uv, fcc, norm, (0, 0, 0, 0), dst, rt, width=1080).ravel()
+    ref, ow, oh = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=fcc, normalization=norm, nthreads=8, width=1080)
+    assert (ow, oh) == dst and got.dtype == ref.dtype and got.size == ref.size
+    if got.dtype == np.uint8:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"max ulp {ulp_diff(np.abs(got), np.abs(ref))}"
+
+
+@pytest.mark.parametrize("fcc", [Y800, NV12, UYVY, YUV444, HSV])
+def test_format_batch_larger_than_one_launch(vpp, oracle, fcc):
+    """70 frames = two launches (64 + 6) of each pass; every frame must land in its own output."""
+    import tensor_stream as ts
+    n = 70
+    frames = [synth_nv12(320, 240, seed=900 + i) for i in range(n)]
+    ys = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    uvs = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    fp = ts.FrameParameters(width=160, height=120, resize_type=1, pixel_format=fcc, normalization=False)
+    out = vpp.convert_batch(ys, uvs, fp)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in (0, 1, 63, 64, 69):
+        ref, _, _ = oracle.convert(frames[i][0], frames[i][1], dst=(160, 120), resize_type=1, fourcc=fcc, normalization=False)
+        got = out[i].ravel()
+        assert got.dtype == ref.dtype
+        assert np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got, ref.view(np.uint32) if ref.dtype == np.float32 else ref)
