@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets")
     ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
+    ap.add_argument("--per-call", type=int, default=0, help="frames per C-ABI call (default: the whole batch); 1 = the reference's one Convert per frame")
+    ap.add_argument("--graph", action="store_true", help="capture a step's calls in a hipGraph and replay it (launch-bound small calls)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -158,11 +160,32 @@ def main():
             sys.exit(2)
 
     # descriptor arrays are built once per buffer set; a step is then a single C-ABI call
-    batches = [vpp.make_batch(ys, uvs, fp, out=out, width=src_w) for (ys, uvs, out) in sets]
+    F = args.per_call if 0 < args.per_call < B else B
+    batches = [[vpp.make_batch(ys[k:k + F], uvs[k:k + F], fp, out=out[k:k + F], width=src_w) for k in range(0, B, F)] for (ys, uvs, out) in sets]
     cur_stream = torch.cuda.current_stream(dev).cuda_stream
 
+    def issue(i, stream):
+        for b in batches[i % len(batches)]:
+            vpp.run_batch(b, stream)
+
+    graphs = []
+    if args.graph:  # one graph per buffer set, captured on a side stream, replayed on the current one
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for i in range(len(batches)):
+                issue(i, side.cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(batches)):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                issue(i, side.cuda_stream)
+            graphs.append(gr)
+
     def step(i):
-        vpp.run_batch(batches[i % len(batches)], cur_stream)
+        if graphs:
+            graphs[i % len(graphs)].replay()
+        else:
+            issue(i, cur_stream)
 
     for i in range(args.warmup):
         step(i)
@@ -187,7 +210,7 @@ def main():
         wall, dev_ms = tt[0].item(), tt[1].item()
 
     if rank == 0:
-        launches_per_step = (B + 63) // 64
+        launches_per_step = ((F + 63) // 64) * (B // F) + ((B % F + 63) // 64)
         frames = B * args.steps * world
         kernel_ms = dev_ms / (args.steps * launches_per_step)  # avg launch duration from HIP events
         frames_per_launch = B / launches_per_step
@@ -200,7 +223,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if norm else "u8", "data": "synthetic",
             "config": {"workload": f"{src_w}x{src_h} NV12 (pitch {pitch}) crop{list(crop)} -> {dst[0] or src_w}x{dst[1] or src_h} "
                                    f"{rt if dst[0] else 'no-resize'} -> {fcc} {planes} {'fp32 /255' if norm else 'uint8'}",
-                       "name": args.workload, "frames_per_step": B, "frames_per_launch": frames_per_launch,
+                       "name": args.workload, "frames_per_step": B, "frames_per_launch": frames_per_launch, "hip_graph": bool(graphs),
                        "buffer_sets": len(sets), "working_set_MiB": round(ws_mib, 1), "sharding": f"frames/{world} ranks, no data collective",
                        "parity": parity},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

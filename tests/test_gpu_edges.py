@@ -129,3 +129,35 @@ def test_merged_fp32_store_exchange(oracle, monkeypatch, shape):
         conv(v, oracle, y, uv, width=1080, crop=(121, 65, 601, 401), planes=1, norm=True, fourcc=1)
     finally:
         v.Close()
+
+
+@pytest.mark.parametrize("rt,fourcc", [(1, 2), (2, 2), (3, 2), (1, 0), (3, 5)])
+def test_convert_is_hip_graph_capturable(vpp, oracle, rt, fourcc):
+    """After prepare() the whole call is kernel launches on the caller's stream -- no allocation, no
+    synchronisation, no host->device copy -- so a caller can capture it in a hipGraph (the remedy for
+    launch-bound single-frame conversion) and replay it on new frame contents."""
+    import tensor_stream as ts
+    frames = [synth_nv12(640, 360, seed=300 + i) for i in range(4)]
+    ys = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    uvs = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    fp = ts.FrameParameters(width=424, height=240, resize_type=rt, pixel_format=fourcc, normalization=True)
+    vpp.prepare(fp, 640, 360)
+    batch = vpp.make_batch(ys, uvs, fp)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        vpp.run_batch(batch)  # warm-up on the capture stream: two-pass formats grow their per-stream scratch buffer here
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        vpp.run_batch(batch)
+    # new contents in the same buffers, then replay
+    frames2 = [synth_nv12(640, 360, seed=400 + i) for i in range(4)]
+    ys.copy_(torch.from_numpy(np.stack([f[0] for f in frames2])))
+    uvs.copy_(torch.from_numpy(np.stack([f[1] for f in frames2])))
+    batch["out"].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    out = batch["out"].cpu().numpy()
+    for i in range(4):
+        ref, _, _ = oracle.convert(frames2[i][0], frames2[i][1], dst=(424, 240), resize_type=rt, fourcc=fourcc, normalization=True)
+        assert np.array_equal(out[i].ravel().view(np.uint32), ref.view(np.uint32))
