@@ -410,7 +410,8 @@ __device__ __forceinline__ void st4o(uint8_t *base, uint32_t off, float a, float
 // 4-byte uint8 stores are always plain: `sc1` turned each into its own fabric write (-36 %), non-temporal bought nothing
 __device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int) { *(uint32_t *)(base + off) = v; }
 // Four integer-valued floats -> packed bytes with v_cvt_pk_u8_f32 (one instruction per byte; it saturates to
-// [0, 255], so the uint8 paths need no separate clamp after the truncation)
+// [0, 255], so the uint8 paths need no separate clamp after the truncation; it rounds to nearest, so the
+// truncation itself stays -- measured: without v_trunc the parity tests fail)
 __device__ __forceinline__ uint32_t pack_u8x4(float a, float b, float c, float e) {
     uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(a, 0u, 0u);
     r = __builtin_amdgcn_cvt_pk_u8_f32(b, 1u, r);

@@ -129,3 +129,31 @@ def test_av_crc_helper_known_answer(oracle):
     """CRC-32/MPEG-2 of "123456789" is 0x0376E6E7; av_crc keeps the state byte-swapped [ext, unverified]."""
     v = oracle.av_crc32_ieee(np.frombuffer(b"123456789", np.uint8))
     assert v == int.from_bytes((0x0376E6E7).to_bytes(4, "big"), "little")
+
+
+def test_two_op_division_by_255_is_exact_for_sixteenths():
+    """The HIP kernels replace the IEEE `x / 255` by e = x*lo; q = fma(x, hi, e) with 1/255 = hi + lo
+    (vpp_kernels.hip norm255, vpp_formats.hip div255).  Every value they normalise is an integer or a multiple of
+    1/16 in [0, 255]; for all 4081 of them the two-op form equals the correctly rounded quotient (exact rational
+    arithmetic, round-to-nearest-even to 24 bits)."""
+    from fractions import Fraction as Fr
+
+    def fl32(q):
+        if q == 0:
+            return Fr(0)
+        sign, q, e = (1 if q > 0 else -1), abs(q), 0
+        while q / Fr(2) ** e >= 2 ** 24:
+            e += 1
+        while q / Fr(2) ** e < 2 ** 23:
+            e -= 1
+        m = q / Fr(2) ** e
+        n = m.numerator // m.denominator
+        r = m - n
+        if r > Fr(1, 2) or (r == Fr(1, 2) and n % 2 == 1):
+            n += 1
+        return sign * n * Fr(2) ** e
+
+    hi, lo = Fr(float.fromhex("0x1.010102p-8")), Fr(float.fromhex("-0x1.fdfdfep-33"))
+    for k in range(255 * 16 + 1):
+        x = Fr(k, 16)
+        assert fl32(x * hi + fl32(x * lo)) == fl32(x / 255), k
