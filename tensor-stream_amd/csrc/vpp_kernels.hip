@@ -1577,18 +1577,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-    // small workgroups (large footprints) must keep many chunks per lane in flight, or the staging
-    // is latency-bound: LDS-DMA issues them all without holding registers; the register path keeps
-    // 16 + 8 chunks per lane for 64 threads, 4 + 2 for 256
+    // LDS-DMA issues every chunk without holding registers; the register path (TSVPP_DMA=0, or a layout that
+    // only fits compact) keeps 4 + 2 chunks per lane in flight.
+    // (Deeper variants for small workgroups cost the WHOLE kernel 168 VGPRs = 3 waves per SIMD, although
+    // the DMA path that normally runs needs fewer than 100.)
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
         stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
         stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
-    } else if (nthreads <= 64)
-        stage_planes<16, 8>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
-    else if (nthreads <= 128)
-        stage_planes<8, 4>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
-    else
+    } else
         stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     const int ntab = tw + (tw >> 1) + th + (th >> 1) + d.lds_rows_y + d.lds_rows_uv;
     for (int e = threadIdx.x; e < ntab; e += nthreads) {
