@@ -153,6 +153,7 @@ struct tsvpp_ctx {
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
     float area_direct_min = 2.0f;   // TSVPP_AREA_DIRECT_MIN
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
+    int area2 = 1;                  // TSVPP_AREA2
     int rpt = 2;                    // TSVPP_RPT
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
@@ -318,6 +319,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
@@ -452,6 +454,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
     d.bicubic_sep = ctx->bicubic_sep;
+    d.area2_pref = ctx->area2;
     d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;

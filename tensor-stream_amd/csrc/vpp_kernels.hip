@@ -1092,6 +1092,132 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 }
 
 // ----------------------------------------------------------------------------------------------
+// AREA down-scale below 2x with weights that are not dyadic (1440p -> 1080p: 4/3; 1080p -> 800x450: 2.4 is not, 1.35 is ...):
+// ceil(ratio) = 2 taps per axis, so this is the 2x2-tap skeleton once more -- staged footprint, per-workgroup
+// tables, float pairs -- with the reference's weighted box instead of the lerp (src/Resize.cu:160-178):
+//     sum = 0; div = 0; for a in rows: for b in cols: wgt = wx[b] * wy[a]; div += wgt; sum += p[a][b] * wgt
+//     out = (int)(sum / div)
+// in exactly that order (the initial 0 + x is exact).  Each tile column / row looks its pattern row up ONCE
+// (j % nx, i % ny) instead of once per pixel, and the division is the only IEEE division left per value.
+struct A2XEntry { int off; float w0, w1; int pad; }; // LDS byte offset from the row base, the two column weights
+struct A2YEntry { int top, bot; float w0, w1; };     // LDS row bases of rows y and y + 1, the two row weights
+
+__device__ __forceinline__ f2 area2_pair(f2 A, f2 B, f2 C, f2 D, f2 wx0, f2 wx1, float wy0, float wy1) {
+    const f2 y0 = { wy0, wy0 }, y1 = { wy1, wy1 };
+    f2 wgt = wx0 * y0;
+    f2 div = wgt;
+    f2 sum = A * wgt;
+    wgt = wx1 * y0;
+    div = div + wgt;
+    sum = sum + B * wgt;
+    wgt = wx0 * y1;
+    div = div + wgt;
+    sum = sum + C * wgt;
+    wgt = wx1 * y1;
+    div = div + wgt;
+    sum = sum + D * wgt;
+    f2 q;
+    q.x = sum.x / div.x;
+    q.y = sum.y / div.y;
+    return trunc2(q);
+}
+
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int tw = d.tx * PXW, th = d.ty * PXH * d.rpt;
+    const Footprint f = tile_footprint<M_AREA_DOWN>(d, id);
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    A2XEntry *xtab = (A2XEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    A2XEntry *cxtab = xtab + tw;
+    A2YEntry *ytab = (A2YEntry *)(cxtab + (tw >> 1));
+    A2YEntry *cytab = ytab + th;
+
+    const uint8_t *ay, *auv;
+    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
+    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
+    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
+    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
+    if (d.dma) {
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+    } else {
+        stage_planes<2, 1>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
+    }
+    const int ntab = tw + (tw >> 1) + th + (th >> 1);
+    for (int e = threadIdx.x; e < ntab; e += nthreads) {
+        if (e < tw + (tw >> 1)) { // columns: luma then chroma pairs -- the SAME formulas and pattern rows on their own index
+            const bool chroma = e >= tw;
+            const int k = chroma ? e - tw : e;
+            const int j = (chroma ? (f.j_first >> 1) : f.j_first) + k;
+            const float *w = d.patx + (j % d.nx) * d.rx;
+            const int x = (int)(d.xr * (float)j);
+            if (!chroma) xtab[k] = A2XEntry{ x - f.xlo, w[0], w[1], 0 };
+            else cxtab[k] = A2XEntry{ 2 * (x - f.cxlo), w[0], w[1], 0 };
+        } else {
+            const int q = e - tw - (tw >> 1);
+            const bool chroma = q >= th;
+            const int k = chroma ? q - th : q;
+            const int i = (chroma ? (f.i_first >> 1) : f.i_first) + k;
+            const float *w = d.paty + (i % d.ny) * d.ry;
+            const LdsPlane &pl = chroma ? puv : py;
+            const int r0 = (int)(d.yr * (float)i) - (chroma ? f.cylo : f.ylo), r1 = r0 + 1;
+            const A2YEntry en = { r0 * pl.lp + ((pl.m0 + r0 * pl.pm) & 15), r1 * pl.lp + ((pl.m0 + r1 * pl.pm) & 15), w[0], w[1] };
+            if (!chroma) ytab[k] = en;
+            else cytab[k] = en;
+        }
+    }
+    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = f.j_first + lx * PXW;
+    if (j0 >= d.dst_w) return;
+    A2XEntry xe[PXW], cxe[2];
+#pragma unroll
+    for (int c = 0; c < PXW; c++) xe[c] = xtab[lx * PXW + c];
+    cxe[0] = cxtab[lx * 2];
+    cxe[1] = cxtab[lx * 2 + 1];
+    for (int rp = 0; rp < d.rpt; rp++) {
+        const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
+        if (i0 >= d.dst_h) break;
+        float Uf[2], Vf[2], Yf[PXH][PXW];
+        {
+            const A2YEntry ye = cytab[lyr];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint8_t *top = lds_uv + ye.top + cxe[c].off, *bot = lds_uv + ye.bot + cxe[c].off;
+                const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
+                const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
+                const f2 v = area2_pair(A, B, C, D, (f2){ cxe[c].w0, cxe[c].w0 }, (f2){ cxe[c].w1, cxe[c].w1 }, ye.w0, ye.w1);
+                Uf[c] = v.x;
+                Vf[c] = v.y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PXH; r++) {
+            const A2YEntry ye = ytab[lyr * PXH + r];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint8_t *t0 = lds_y + ye.top + xe[2 * p].off, *t1 = lds_y + ye.top + xe[2 * p + 1].off;
+                const uint8_t *b0 = lds_y + ye.bot + xe[2 * p].off, *b1 = lds_y + ye.bot + xe[2 * p + 1].off;
+                const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
+                const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
+                const f2 v = area2_pair(A, B, C, D, (f2){ xe[2 * p].w0, xe[2 * p + 1].w0 }, (f2){ xe[2 * p].w1, xe[2 * p + 1].w1 }, ye.w0, ye.w1);
+                Yf[r][2 * p] = v.x;
+                Yf[r][2 * p + 1] = v.y;
+            }
+        }
+        color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // BICUBIC kernel.  Same skeleton as the 2x2-tap kernel: footprint staged by LDS-DMA, per-workgroup
 // tables -- here each output column / row gets its four tap offsets (the reference's edge rule,
 // src/Resize.cu:32-43, is baked into the offsets: no clamping at tap time) and its four Keys
@@ -2132,6 +2258,12 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 return hipGetLastError();
             }
         }
+        if constexpr (MODE == M_AREA_DOWN) {
+            if (staged && d.area2) {
+                hipLaunchKernelGGL((vpp_area2_kernel<OUT>), grid, block, lds_bytes, stream, d, t);
+                return hipGetLastError();
+            }
+        }
         if (staged) {
             hipLaunchKernelGGL((vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes, stream, d, t);
             return hipGetLastError();
@@ -2241,7 +2373,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
             const bool sep = mode == M_BICUBIC && d.bicubic_sep && sh[1] >= 2;
-            int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
+            const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx == 2 && d.ry == 2 && d.area2_pref;
+            int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep || area2) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
             while (rpt_max > 1 && workgroups(sh, rpt_max) < 16L * d.num_cus) rpt_max--;
@@ -2272,6 +2405,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
                         need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
                                 (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
+                    if (area2) // column / row tables of the 2x2 float AREA kernel
+                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(A2XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(A2YEntry);
                     if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
                         need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(YEntry);
                     if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights (+ the H planes of the separable kernel)
@@ -2294,6 +2429,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     d.lds_slot_uv = slot_shift_for(cpr_uv);
                     d.dma = dma ? 1 : 0;
                     if (mode == M_BICUBIC) d.bicubic_sep = sep ? 1 : 0;
+                    d.area2 = area2 ? 1 : 0;
                 }
             }
         }

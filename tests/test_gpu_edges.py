@@ -161,3 +161,15 @@ def test_convert_is_hip_graph_capturable(vpp, oracle, rt, fourcc):
     for i in range(4):
         ref, _, _ = oracle.convert(frames2[i][0], frames2[i][1], dst=(424, 240), resize_type=rt, fourcc=fourcc, normalization=True)
         assert np.array_equal(out[i].ravel().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("src,dst", [((2560, 1440), (1920, 1080)), ((1080, 608), (1068, 600)), ((1080, 608), (640, 320)),
+                                     ((1000, 562), (588, 500)), ((640, 360), (636, 182))])
+def test_area_float_2x2_kernel(vpp, oracle, src, dst):
+    """AREA down-scales below 2x with non-dyadic weights (4/3, 1.01, 1.69 x 1.9, ...): the 2x2 float kernel; the last
+    case mixes it with a ratio >= 2 on the other axis (generic staged kernel)."""
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0], pitch=(src[0] + 63) // 64 * 64 + 3)
+    conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, planes=0, norm=True)
+    conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, planes=1, norm=False)
+    conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, fourcc=0, norm=True)
+    conv(vpp, oracle, y, uv, width=src[0], crop=(3, 2, src[0] - 5, src[1] - 2), dst=(dst[0] - 4, dst[1] - 2), rt=3, planes=0, norm=False)
