@@ -209,7 +209,8 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     switch (p->fourcc) {
     case TSVPP_RGB24: pl.swap_rb = 0; break;
     case TSVPP_BGR24: pl.swap_rb = 1; break;
-    case TSVPP_Y800: case TSVPP_NV12: case TSVPP_UYVY: case TSVPP_YUV444: case TSVPP_HSV: break; // via the NV12 intermediate
+    case TSVPP_Y800: case TSVPP_NV12: case TSVPP_HSV: break;  // output flavours of the fused kernels
+    case TSVPP_UYVY: case TSVPP_YUV444: break;                // second pass over the (resized) NV12
     default: return TSVPP_UNSUPPORTED;
     }
     if (p->planes != TSVPP_PLANAR && p->planes != TSVPP_MERGED) return TSVPP_UNSUPPORTED;
@@ -218,6 +219,10 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     pl.f32 = f32;
     pl.out = f32 ? (p->planes == TSVPP_PLANAR ? O_F32_PLANAR : O_F32_MERGED)
                  : (p->planes == TSVPP_PLANAR ? O_U8_PLANAR : O_U8_MERGED);
+    if (p->fourcc == TSVPP_Y800) pl.out = f32 ? O_Y800_F32 : O_Y800_U8;
+    else if (p->fourcc == TSVPP_NV12) pl.out = f32 ? O_NV12_F32 : O_NV12_U8;
+    else if (p->fourcc == TSVPP_HSV) pl.out = O_HSV_F32;
+    else if (p->fourcc == TSVPP_UYVY || p->fourcc == TSVPP_YUV444) pl.out = O_NV12_U8; // pass 1
     // channelsByFourCC: 1.5 for NV12 (src/VideoProcessor.cpp:4-14)
     const size_t elems = p->fourcc == TSVPP_NV12 ? (size_t)pl.dst_w * pl.dst_h * 3 / 2
                                                  : (size_t)(tsvpp_channels(p->fourcc) * (float)pl.dst_w) * (size_t)pl.dst_h;
@@ -253,6 +258,7 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
         if (hipMalloc((void **)&t.dev4, pad.size() * sizeof(float)) != hipSuccess ||
             hipMemcpy(t.dev4, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(t.dev);
+            if (t.dev4) (void)hipFree(t.dev4);
             return TSVPP_ERROR;
         }
     }
@@ -511,12 +517,8 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         }
         scratch = slot.first;
     }
-    OutKind out_kind = pl.out;
-    if (pl.fourcc == TSVPP_Y800) out_kind = pl.f32 ? O_Y800_F32 : O_Y800_U8;
-    else if (pl.fourcc == TSVPP_NV12) out_kind = pl.f32 ? O_NV12_F32 : O_NV12_U8;
-    else if (pl.fourcc == TSVPP_HSV) out_kind = O_HSV_F32;
+    const OutKind out_kind = pl.out;
     if (two_pass) {
-        out_kind = O_NV12_U8;
         vec = (pl.dst_w % 4) == 0; // scratch frames are 256-byte aligned
         if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     }
