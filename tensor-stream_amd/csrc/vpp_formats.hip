@@ -108,18 +108,18 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_uyvy(const FrameTable t, c
         }
     }
     T *o = (T *)t.out[f] + ((size_t)i * s.w + j) * 2;
-    if constexpr (PAIRS == 2 && sizeof(T) == 1) {
-        uint2 w;
-        w.x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
-        w.y = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
-        __builtin_nontemporal_store(w.x, (uint32_t *)o);
-        __builtin_nontemporal_store(w.y, (uint32_t *)o + 1);
+    if constexpr (PAIRS == 2 && sizeof(T) == 1) { // one 8-byte store per lane: a wave instruction covers 512 contiguous bytes
+        const uint64_t lo = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        const uint64_t hi = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+        __builtin_nontemporal_store(lo | (hi << 32), (uint64_t *)o);
     } else if constexpr (PAIRS == 2) {
+        // 32 bytes per lane in two 16-byte stores: each instruction writes half of every line, so plain stores
+        // (L2 combines the halves; non-temporal ones would go out as partial lines, cf. MergedRun in vpp_kernels.hip)
         typedef float vf4 __attribute__((ext_vector_type(4)));
         const vf4 a = { fin<float>(v[0]), fin<float>(v[1]), fin<float>(v[2]), fin<float>(v[3]) };
         const vf4 b = { fin<float>(v[4]), fin<float>(v[5]), fin<float>(v[6]), fin<float>(v[7]) };
-        __builtin_nontemporal_store(a, (vf4 *)o);
-        __builtin_nontemporal_store(b, (vf4 *)o + 1);
+        *(vf4 *)o = a;
+        *((vf4 *)o + 1) = b;
     } else {
 #pragma unroll
         for (int c = 0; c < 4; c++) o[c] = fin<T>(v[c]);
@@ -168,25 +168,35 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444(const FrameTable t,
     const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
     const size_t wh = (size_t)s.w * s.h;
     int c[PAIRS + 3][2]; // chroma of pairs -1 .. PAIRS + 1 relative to this thread's first
-    bool fast = false;
-    if constexpr (PAIRS == 2) fast = (j >= 4) && (j + 8 <= s.w);
-    if (fast) { // all five pairs lie in row i: bytes j - 2 .. j + 7 of the chroma row(s), three loads per tap row
-        if constexpr (PAIRS == 2) {
-            int l[4], m[4], r[4];
-            if (g.aligned4) {
-                chroma_422x4<true>(s, i, j - 4, l);
-                chroma_422x4<true>(s, i, j, m);
-                chroma_422x4<true>(s, i, j + 4, r);
-            } else {
-                chroma_422x4<false>(s, i, j - 4, l);
-                chroma_422x4<false>(s, i, j, m);
-                chroma_422x4<false>(s, i, j + 4, r);
+    if constexpr (PAIRS == 2) {
+        // bytes j - 2 .. j + 7 of the chroma row(s): three loads per tap row (columns clamped into the row); the
+        // pairs that fall off either end of the row are then patched from the neighbouring rows (edge lanes only)
+        int l[4], m[4], r[4];
+        const int jl = max(j - 4, 0), jr = min(j + 4, s.w - 4);
+        if (g.aligned4) {
+            chroma_422x4<true>(s, i, jl, l);
+            chroma_422x4<true>(s, i, j, m);
+            chroma_422x4<true>(s, i, jr, r);
+        } else {
+            chroma_422x4<false>(s, i, jl, l);
+            chroma_422x4<false>(s, i, j, m);
+            chroma_422x4<false>(s, i, jr, r);
+        }
+        c[0][0] = l[2], c[0][1] = l[3];
+        c[1][0] = m[0], c[1][1] = m[1];
+        c[2][0] = m[2], c[2][1] = m[3];
+        c[3][0] = r[0], c[3][1] = r[1];
+        c[4][0] = r[2], c[4][1] = r[3];
+        if (j == 0) {
+            c[0][0] = uyvy_chroma(s, i, -2, 0);
+            c[0][1] = uyvy_chroma(s, i, -2, 1);
+        }
+        if (j + 4 >= s.w) {
+#pragma unroll
+            for (int k = 3; k < 5; k++) {
+                c[k][0] = uyvy_chroma(s, i, j + 2 * (k - 1), 0);
+                c[k][1] = uyvy_chroma(s, i, j + 2 * (k - 1), 1);
             }
-            c[0][0] = l[2], c[0][1] = l[3];
-            c[1][0] = m[0], c[1][1] = m[1];
-            c[2][0] = m[2], c[2][1] = m[3];
-            c[3][0] = r[0], c[3][1] = r[1];
-            c[4][0] = r[2], c[4][1] = r[3];
         }
     } else {
 #pragma unroll
@@ -204,17 +214,22 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444(const FrameTable t,
         yv[0] = fin<T>(s.y[(size_t)i * s.py + j]);
         yv[1] = fin<T>(s.y[(size_t)i * s.py + j + 1]);
     }
+    // The reference tests its flat source index against the ends of the UYVY buffer (src - 7 + shift < 0 and
+    // src + 5 + shift > 2 w h - 1 with src = 2 idx + 1, shift = 0 / 2 for U / V, src/ColorConversion.cu:150-160):
+    // for both components that is "the frame's first odd pixel" and "its last two odd pixels".  w h < 2^31 (the ABI
+    // bounds the output at 4 GiB), so the flat index fits 32 bits.
+    const uint32_t wh32 = (uint32_t)s.w * (uint32_t)s.h, row0 = (uint32_t)i * (uint32_t)s.w + (uint32_t)j;
 #pragma unroll
     for (int p = 0; p < PAIRS; p++) {
-        const long idx0 = (long)i * s.w + j + 2 * p, idx1 = idx0 + 1, src = 2 * idx1 + 1;
+        const uint32_t idx1 = row0 + 2 * p + 1;
+        const bool first = idx1 == 1u, last2 = idx1 + 3u >= wh32;
         uo[2 * p] = fin<T>(c[p + 1][0]);
         vo[2 * p] = fin<T>(c[p + 1][1]);
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
-            const int shift = 2 * comp;
             const int p1 = c[p + 1][comp], p2 = c[p + 2][comp];
-            const int p3 = (src - 7 + shift < 0) ? p1 : c[p][comp];
-            const int p4 = (src + 5 + shift > (long)(2 * wh) - 1) ? p2 : c[p + 3][comp];
+            const int p3 = first ? p1 : c[p][comp];
+            const int p4 = last2 ? p2 : c[p + 3][comp];
             (comp ? vo : uo)[2 * p + 1] = yuv444_odd<T>(p1, p2, p3, p4);
         }
     }
