@@ -145,15 +145,18 @@ __device__ __forceinline__ f2 cubic4_pair(float w0, float w1, const float c0[4],
     const f2 dd = s - r;
     r.x = __builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f);
     r.y = __builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);
-    if (fabsf(dd.x) > 0.5f - CUBIC_DELTA) {
-        double c[4];
-        cubic_coeffs((double)w0, c);
-        r.x = (float)cubic4(c, q0[0], q0[1], q0[2], q0[3]);
-    }
-    if (fabsf(dd.y) > 0.5f - CUBIC_DELTA) {
-        double c[4];
-        cubic_coeffs((double)w1, c);
-        r.y = (float)cubic4(c, q1[0], q1[1], q1[2], q1[3]);
+    const bool tie0 = fabsf(dd.x) > 0.5f - CUBIC_DELTA, tie1 = fabsf(dd.y) > 0.5f - CUBIC_DELTA;
+    if (tie0 || tie1) { // one (rarely taken) branch for the pair
+        if (tie0) {
+            double c[4];
+            cubic_coeffs((double)w0, c);
+            r.x = (float)cubic4(c, q0[0], q0[1], q0[2], q0[3]);
+        }
+        if (tie1) {
+            double c[4];
+            cubic_coeffs((double)w1, c);
+            r.y = (float)cubic4(c, q1[0], q1[1], q1[2], q1[3]);
+        }
     }
     return r;
 }
@@ -2365,9 +2368,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
     // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
     // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
-    // 224^2 / 300^2 / 640^2, 4K -> 640x360): BILINEAR gathers win from xr*yr ~ 16 (3.5x at 41), BICUBIC from ~ 30.
+    // 224^2 / 300^2 / 640^2, 4K -> 640x360; C3: 720p crop -> 256^2 = 14, gathers +8 %): BILINEAR gathers win from
+    // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
-    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 16.0f) || (mode == M_BICUBIC && ratio_area >= 30.0f);
+    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && ratio_area >= 30.0f);
     if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
