@@ -151,7 +151,9 @@ struct tsvpp_ctx {
     int nt_stores = -1, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
     int persist = 0, num_cus = 256; // TSVPP_PERSIST
-    float area_direct_min = 2.0f;   // TSVPP_AREA_DIRECT_MIN
+    // dyadic AREA reads straight from global memory from this ratio on (both axes); below it the LDS kernel wins
+    // (measured after its VGPR fix: 2x 501 k vs 368 k fps, 3x 743 k vs 621 k, 4x 162 k vs 251 k)
+    float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int area2 = 1;                  // TSVPP_AREA2
     int rpt = 2;                    // TSVPP_RPT

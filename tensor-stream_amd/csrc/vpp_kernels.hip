@@ -2332,9 +2332,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
         d.yr >= d.area_direct_min)
         d.area_direct = 1;
-    else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
-             d.yr >= d.area_direct_min && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
-        d.area_direct = 2; // float weights
+    else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= fminf(d.area_direct_min, 2.0f) &&
+             d.yr >= fminf(d.area_direct_min, 2.0f) && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
+        d.area_direct = 2; // float weights: from 2x already (below it the 2x2 float kernel; the alternative here is the generic sampler)
     else
         d.area_direct = 0;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);

@@ -173,3 +173,13 @@ def test_area_float_2x2_kernel(vpp, oracle, src, dst):
     conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, planes=1, norm=False)
     conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, fourcc=0, norm=True)
     conv(vpp, oracle, y, uv, width=src[0], crop=(3, 2, src[0] - 5, src[1] - 2), dst=(dst[0] - 4, dst[1] - 2), rt=3, planes=0, norm=False)
+
+
+@pytest.mark.parametrize("src,dst", [((1920, 1080), (960, 540)), ((1080, 600), (360, 200)), ((1080, 600), (432, 240)),
+                                     ((1280, 720), (400, 240)), ((1920, 1080), (640, 540)), ((1600, 900), (400, 300))])
+def test_area_dyadic_lds_kernel_ratios_2_to_3p5(vpp, oracle, src, dst):
+    """Dyadic AREA ratios from 2 to 3.5 (2, 3, 2.5, 3.2 x 3, 3 x 2, 4 x 3) run on the LDS kernel with 2, 3 or 4 taps
+    per axis (v_dot4 over one weight dword); from 3.5 in both axes the direct kernel takes over."""
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] * 3 + dst[1], pitch=src[0] + 6)
+    conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, planes=0, norm=True)
+    conv(vpp, oracle, y, uv, width=src[0], crop=(2, 2, src[0] - 2, src[1] - 2), dst=dst, rt=3, planes=1, norm=False)

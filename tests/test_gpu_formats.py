@@ -66,7 +66,8 @@ def test_batch_of_two_pass_format(vpp, oracle):
                                     ((1280, 720), 1),     # BILINEAR up: 2x2-tap kernel
                                     ((720, 404), 2),      # BICUBIC: table kernel
                                     ((540, 304), 3),      # AREA 2x: dyadic kernels
-                                    ((360, 152), 3),      # AREA 3x / 4x: direct dyadic kernel
+                                    ((216, 152), 3),      # AREA 5x / 4x: direct dyadic kernel
+                                    ((360, 304), 3),      # AREA 3x / 2x: dyadic LDS kernel, 3 and 2 vertical taps
                                     ((432, 244), 3),      # AREA 2.5x / 2.49x: direct float kernel
                                     ((1440, 808), 3),     # AREA up: bilinear variant
                                     ((120, 76), 1)])      # BILINEAR 9x / 8x: sparse gather
