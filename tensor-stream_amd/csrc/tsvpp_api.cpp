@@ -154,6 +154,7 @@ struct tsvpp_ctx {
     // dyadic AREA reads straight from global memory from this ratio on (both axes); below it the LDS kernel wins
     // (measured after its VGPR fix: 2x 501 k vs 368 k fps, 3x 743 k vs 621 k, 4x 162 k vs 251 k)
     float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
+    float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int area2 = 1;                  // TSVPP_AREA2
     int rpt = 2;                    // TSVPP_RPT
@@ -326,6 +327,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
+    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     {
@@ -427,7 +429,10 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
-    bool vec = (pl.dst_w % 4) == 0;
+    // vector-store kernels: 16-byte aligned outputs; dst_w is even, and when it is 4 k + 2 the last thread tile of a row
+    // stores its two columns on the scalar path (rows then start 8 bytes / 2 bytes off the vector alignment, which
+    // global stores tolerate)
+    bool vec = true;
     for (int f = 0; f < n; f++) {
         if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
         if (in[f].width != in[0].width || in[f].height != in[0].height) return TSVPP_UNSUPPORTED;
@@ -461,6 +466,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.dma = ctx->dma;
     d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
+    d.area_direct_fmin = ctx->area_direct_fmin;
     d.bicubic_sep = ctx->bicubic_sep;
     d.area2_pref = ctx->area2;
     d.num_cus = ctx->num_cus;
@@ -521,7 +527,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     }
     const OutKind out_kind = pl.out;
     if (two_pass) {
-        vec = (pl.dst_w % 4) == 0; // scratch frames are 256-byte aligned
+        vec = true; // scratch frames are 256-byte aligned
         if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     }
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {

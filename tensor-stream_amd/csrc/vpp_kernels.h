@@ -66,6 +66,7 @@ struct LaunchDesc {
     int shape_tx, shape_ty; // != 0: force the workgroup shape
     int area_direct;        // (launch_fused) dyadic AREA straight from global memory
     float area_direct_min;  // use it when both ratios are >= this (0 = never)
+    float area_direct_fmin; // the same for the float-weight direct kernel
     int rpt_pref;           // preferred row pairs per thread for the 2x2-tap kernel (TSVPP_RPT)
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
@@ -84,7 +85,8 @@ struct LaunchDesc {
 enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_NV12_F32, O_Y800_U8, O_Y800_F32, O_HSV_F32, O_COUNT };
 
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
-// store path (needs dst_w % 4 == 0 and 16-byte aligned outputs).  Returns hipError_t.
+// store path (needs 16-byte aligned outputs; a row's last thread tile stores scalar when dst_w = 4 k + 2).
+// Returns hipError_t.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream);
 
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);

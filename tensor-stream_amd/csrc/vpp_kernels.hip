@@ -564,6 +564,12 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
                                                  typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
+    if constexpr (VEC) { // dst_w = 4 k + 2: the row's last thread tile has two columns; it alone takes the scalar path
+        if (d.dst_w - j0 < PXW) {
+            color_store_tile<OUT, false>(Yf, Uf, Vf, d, out, i0, j0, d.dst_w - j0);
+            return;
+        }
+    }
     if constexpr (OUT == O_NV12_U8 || OUT == O_NV12_F32 || OUT == O_Y800_U8 || OUT == O_Y800_F32) {
         // no colour conversion: the resized samples themselves (fp32: / 255), Y plane then UV plane
         using T = typename OutT<OUT>::type;
@@ -669,14 +675,14 @@ __device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
 // Generic thread tile: samplers (any mode, any reader) -> colour back end.
 template <int MODE, int OUT, bool VEC, class S>
 __device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc &d, typename OutT<OUT>::type *out, int i0, int j0) {
-    const int ncol = VEC ? PXW : min(PXW, d.dst_w - j0); // dst_w is even: 2 or 4
+    const int ncol = min(PXW, d.dst_w - j0); // dst_w is even: 2 or 4 (2 only in the last thread tile of a row)
     const int ci = i0 >> 1, cj0 = j0 >> 1;
     float Uf[2], Vf[2], Yf[PXH][PXW];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         int U = 128, V = 128;
         if constexpr (!kLumaOnly<OUT>)
-            if (VEC || 2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
+            if (2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
         Uf[c] = (float)U;
         Vf[c] = (float)V;
     }
@@ -685,7 +691,7 @@ __device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
             int Y = 0;
-            if (VEC || c < ncol) Y = sample_luma<MODE>(s, d, i0 + r, j0 + c);
+            if (c < ncol) Y = sample_luma<MODE>(s, d, i0 + r, j0 + c);
             Yf[r][c] = (float)Y;
         }
     color_store_tile<OUT, VEC>(Yf, Uf, Vf, d, out, i0, j0, ncol);
@@ -1095,38 +1101,45 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
 }
 
 // ----------------------------------------------------------------------------------------------
-// AREA down-scale below 2x with weights that are not dyadic (1440p -> 1080p: 4/3; 1080p -> 800x450: 2.4 is not, 1.35 is ...):
-// ceil(ratio) = 2 taps per axis, so this is the 2x2-tap skeleton once more -- staged footprint, per-workgroup
-// tables, float pairs -- with the reference's weighted box instead of the lerp (src/Resize.cu:160-178):
+// AREA down-scale with float (non-dyadic) weights and RX x RY <= 3 x 3 taps -- ratios below 3 on both axes that the
+// integer kernels cannot take (4/3: 1440p -> 1080p; 2.25 x 1.69: 1080x608 -> 480x360; 2.4; ...).  The 2x2-tap skeleton
+// once more -- staged footprint, per-workgroup tables, float pairs -- with the reference's weighted box instead of
+// the lerp (src/Resize.cu:160-178):
 //     sum = 0; div = 0; for a in rows: for b in cols: wgt = wx[b] * wy[a]; div += wgt; sum += p[a][b] * wgt
 //     out = (int)(sum / div)
 // in exactly that order (the initial 0 + x is exact).  Each tile column / row looks its pattern row up ONCE
 // (j % nx, i % ny) instead of once per pixel, and the division is the only IEEE division left per value.
-struct A2XEntry { int off; float w0, w1; int pad; }; // LDS byte offset from the row base, the two column weights
-struct A2YEntry { int top, bot; float w0, w1; };     // LDS row bases of rows y and y + 1, the two row weights
+struct AFXEntry { int off; float w[3]; };  // LDS byte offset from the row base, the column weights
+struct AFYEntry { int row; float w[3]; };  // first staged row, the row weights
 
-__device__ __forceinline__ f2 area2_pair(f2 A, f2 B, f2 C, f2 D, f2 wx0, f2 wx1, float wy0, float wy1) {
-    const f2 y0 = { wy0, wy0 }, y1 = { wy1, wy1 };
-    f2 wgt = wx0 * y0;
-    f2 div = wgt;
-    f2 sum = A * wgt;
-    wgt = wx1 * y0;
-    div = div + wgt;
-    sum = sum + B * wgt;
-    wgt = wx0 * y1;
-    div = div + wgt;
-    sum = sum + C * wgt;
-    wgt = wx1 * y1;
-    div = div + wgt;
-    sum = sum + D * wgt;
+template <int RX, int RY>
+__device__ __forceinline__ f2 areaf_pair(const uint8_t *const t0[RY], const uint8_t *const t1[RY], int step, const float wx0[3], const float wx1[3],
+                                         const float wy[3]) {
+    f2 sum = { 0.0f, 0.0f }, div = { 0.0f, 0.0f };
+#pragma unroll
+    for (int a = 0; a < RY; a++) {
+        const f2 y = { wy[a], wy[a] };
+#pragma unroll
+        for (int b = 0; b < RX; b++) {
+            const f2 wgt = (f2){ wx0[b], wx1[b] } * y;
+            const f2 p = { (float)t0[a][b * step], (float)t1[a][b * step] };
+            if (a == 0 && b == 0) { // 0 + x == x
+                div = wgt;
+                sum = p * wgt;
+            } else {
+                div = div + wgt;
+                sum = sum + p * wgt;
+            }
+        }
+    }
     f2 q;
     q.x = sum.x / div.x;
     q.y = sum.y / div.y;
     return trunc2(q);
 }
 
-template <int OUT>
-__global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc d, const FrameTable t) {
+template <int RX, int RY, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_areaf_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
     const TileId id = decode_tile(d);
     if (!id.valid) return;
@@ -1136,10 +1149,12 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc
 
     uint8_t *lds_y = lds_raw;
     uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
-    A2XEntry *xtab = (A2XEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
-    A2XEntry *cxtab = xtab + tw;
-    A2YEntry *ytab = (A2YEntry *)(cxtab + (tw >> 1));
-    A2YEntry *cytab = ytab + th;
+    AFXEntry *xtab = (AFXEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
+    AFXEntry *cxtab = xtab + tw;
+    AFYEntry *ytab = (AFYEntry *)(cxtab + (tw >> 1));
+    AFYEntry *cytab = ytab + th;
+    int *rby = (int *)(cytab + (th >> 1)); // LDS byte offset of every staged luma row (incl. its misalignment)
+    int *rbuv = rby + d.lds_rows_y;
 
     const uint8_t *ay, *auv;
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
@@ -1152,27 +1167,36 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc
     } else {
         stage_planes<2, 1>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     }
-    const int ntab = tw + (tw >> 1) + th + (th >> 1);
+    const int ntab = tw + (tw >> 1) + th + (th >> 1) + d.lds_rows_y + d.lds_rows_uv;
     for (int e = threadIdx.x; e < ntab; e += nthreads) {
-        if (e < tw + (tw >> 1)) { // columns: luma then chroma pairs -- the SAME formulas and pattern rows on their own index
-            const bool chroma = e >= tw;
-            const int k = chroma ? e - tw : e;
+        int k = e;
+        if (k < tw + (tw >> 1)) { // columns: luma then chroma pairs -- the SAME formulas and pattern rows on their own index
+            const bool chroma = k >= tw;
+            if (chroma) k -= tw;
             const int j = (chroma ? (f.j_first >> 1) : f.j_first) + k;
             const float *w = d.patx + (j % d.nx) * d.rx;
             const int x = (int)(d.xr * (float)j);
-            if (!chroma) xtab[k] = A2XEntry{ x - f.xlo, w[0], w[1], 0 };
-            else cxtab[k] = A2XEntry{ 2 * (x - f.cxlo), w[0], w[1], 0 };
-        } else {
-            const int q = e - tw - (tw >> 1);
-            const bool chroma = q >= th;
-            const int k = chroma ? q - th : q;
+            const AFXEntry en = { chroma ? 2 * (x - f.cxlo) : x - f.xlo, { w[0], w[1], RX > 2 ? w[2] : 0.0f } };
+            if (!chroma) xtab[k] = en;
+            else cxtab[k] = en;
+            continue;
+        }
+        k -= tw + (tw >> 1);
+        if (k < th + (th >> 1)) {
+            const bool chroma = k >= th;
+            if (chroma) k -= th;
             const int i = (chroma ? (f.i_first >> 1) : f.i_first) + k;
             const float *w = d.paty + (i % d.ny) * d.ry;
-            const LdsPlane &pl = chroma ? puv : py;
-            const int r0 = (int)(d.yr * (float)i) - (chroma ? f.cylo : f.ylo), r1 = r0 + 1;
-            const A2YEntry en = { r0 * pl.lp + ((pl.m0 + r0 * pl.pm) & 15), r1 * pl.lp + ((pl.m0 + r1 * pl.pm) & 15), w[0], w[1] };
+            const AFYEntry en = { (int)(d.yr * (float)i) - (chroma ? f.cylo : f.ylo), { w[0], w[1], RY > 2 ? w[2] : 0.0f } };
             if (!chroma) ytab[k] = en;
             else cytab[k] = en;
+            continue;
+        }
+        k -= th + (th >> 1);
+        if (k < d.lds_rows_y) rby[k] = k * py.lp + ((py.m0 + k * py.pm) & 15);
+        else {
+            k -= d.lds_rows_y;
+            rbuv[k] = k * puv.lp + ((puv.m0 + k * puv.pm) & 15);
         }
     }
     if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1181,7 +1205,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW;
     if (j0 >= d.dst_w) return;
-    A2XEntry xe[PXW], cxe[2];
+    AFXEntry xe[PXW], cxe[2];
 #pragma unroll
     for (int c = 0; c < PXW; c++) xe[c] = xtab[lx * PXW + c];
     cxe[0] = cxtab[lx * 2];
@@ -1191,27 +1215,38 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area2_kernel(const LaunchDesc
         if (i0 >= d.dst_h) break;
         float Uf[2], Vf[2], Yf[PXH][PXW];
         {
-            const A2YEntry ye = cytab[lyr];
+            const AFYEntry ye = cytab[lyr];
+            int rb[RY];
+#pragma unroll
+            for (int a = 0; a < RY; a++) rb[a] = rbuv[ye.row + a];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const uint8_t *top = lds_uv + ye.top + cxe[c].off, *bot = lds_uv + ye.bot + cxe[c].off;
-                const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
-                const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
-                const f2 v = area2_pair(A, B, C, D, (f2){ cxe[c].w0, cxe[c].w0 }, (f2){ cxe[c].w1, cxe[c].w1 }, ye.w0, ye.w1);
+                const uint8_t *tu[RY], *tv[RY];
+#pragma unroll
+                for (int a = 0; a < RY; a++) {
+                    tu[a] = lds_uv + rb[a] + cxe[c].off;
+                    tv[a] = tu[a] + 1;
+                }
+                const f2 v = areaf_pair<RX, RY>(tu, tv, 2, cxe[c].w, cxe[c].w, ye.w);
                 Uf[c] = v.x;
                 Vf[c] = v.y;
             }
         }
 #pragma unroll
         for (int r = 0; r < PXH; r++) {
-            const A2YEntry ye = ytab[lyr * PXH + r];
+            const AFYEntry ye = ytab[lyr * PXH + r];
+            int rb[RY];
+#pragma unroll
+            for (int a = 0; a < RY; a++) rb[a] = rby[ye.row + a];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const uint8_t *t0 = lds_y + ye.top + xe[2 * p].off, *t1 = lds_y + ye.top + xe[2 * p + 1].off;
-                const uint8_t *b0 = lds_y + ye.bot + xe[2 * p].off, *b1 = lds_y + ye.bot + xe[2 * p + 1].off;
-                const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
-                const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
-                const f2 v = area2_pair(A, B, C, D, (f2){ xe[2 * p].w0, xe[2 * p + 1].w0 }, (f2){ xe[2 * p].w1, xe[2 * p + 1].w1 }, ye.w0, ye.w1);
+                const uint8_t *t0[RY], *t1[RY];
+#pragma unroll
+                for (int a = 0; a < RY; a++) {
+                    t0[a] = lds_y + rb[a] + xe[2 * p].off;
+                    t1[a] = lds_y + rb[a] + xe[2 * p + 1].off;
+                }
+                const f2 v = areaf_pair<RX, RY>(t0, t1, 1, xe[2 * p].w, xe[2 * p + 1].w, ye.w);
                 Yf[r][2 * p] = v.x;
                 Yf[r][2 * p + 1] = v.y;
             }
@@ -1880,8 +1915,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
         int xo[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            qx[c] = d.qx[(cj0 + c) % d.nx];
-            xo[c] = 2 * (int)(d.xr * (float)(cj0 + c));
+            const int cj = min(cj0 + c, (d.dst_w >> 1) - 1); // a row's last thread tile may have two columns: never address past them
+            qx[c] = d.qx[cj % d.nx];
+            xo[c] = 2 * (int)(d.xr * (float)cj);
         }
         uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
         for (int a = 0; a < d.ry; a++) {
@@ -1915,8 +1951,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
         uint32_t w0[PXW], w1[PXW];
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
-            const AreaQRow q = d.qx[(j0 + c) % d.nx];
-            xo[c] = (int)(d.xr * (float)(j0 + c));
+            const int j = min(j0 + c, d.dst_w - 1);
+            const AreaQRow q = d.qx[j % d.nx];
+            xo[c] = (int)(d.xr * (float)j);
             xs[c] = q.sum;
             w0[c] = q.w[0];
             w1[c] = q.w[1];
@@ -1974,8 +2011,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
         const int y0 = (int)(d.yr * (float)ci);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int x0 = 2 * (int)(d.xr * (float)(cj0 + c));
-            const float *wxrow = d.patx4 + ((cj0 + c) % d.nx) * 4 * NK;
+            const int cj = min(cj0 + c, (d.dst_w >> 1) - 1); // a row's last thread tile may have two columns: never address past them
+            const int x0 = 2 * (int)(d.xr * (float)cj);
+            const float *wxrow = d.patx4 + (cj % d.nx) * 4 * NK;
             vf4 wx[NK];
 #pragma unroll
             for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
@@ -2018,8 +2056,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
         vf4 wx[PXW][NK];
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
-            x0[c] = (int)(d.xr * (float)(j0 + c));
-            const float *wxrow = d.patx4 + ((j0 + c) % d.nx) * 4 * NK;
+            const int j = min(j0 + c, d.dst_w - 1);
+            x0[c] = (int)(d.xr * (float)j);
+            const float *wxrow = d.patx4 + (j % d.nx) * 4 * NK;
 #pragma unroll
             for (int k = 0; k < NK; k++) wx[c][k] = *(const vf4a4 *)(wxrow + 4 * k);
         }
@@ -2262,8 +2301,11 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             }
         }
         if constexpr (MODE == M_AREA_DOWN) {
-            if (staged && d.area2) {
-                hipLaunchKernelGGL((vpp_area2_kernel<OUT>), grid, block, lds_bytes, stream, d, t);
+            if (staged && d.area2) { // float weights, at most 3 x 3 taps
+                if (d.rx == 2 && d.ry == 2) hipLaunchKernelGGL((vpp_areaf_kernel<2, 2, OUT>), grid, block, lds_bytes, stream, d, t);
+                else if (d.rx == 3 && d.ry == 2) hipLaunchKernelGGL((vpp_areaf_kernel<3, 2, OUT>), grid, block, lds_bytes, stream, d, t);
+                else if (d.rx == 2 && d.ry == 3) hipLaunchKernelGGL((vpp_areaf_kernel<2, 3, OUT>), grid, block, lds_bytes, stream, d, t);
+                else hipLaunchKernelGGL((vpp_areaf_kernel<3, 3, OUT>), grid, block, lds_bytes, stream, d, t);
                 return hipGetLastError();
             }
         }
@@ -2332,9 +2374,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
         d.yr >= d.area_direct_min)
         d.area_direct = 1;
-    else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= fminf(d.area_direct_min, 2.0f) &&
-             d.yr >= fminf(d.area_direct_min, 2.0f) && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
-        d.area_direct = 2; // float weights: from 2x already (below it the 2x2 float kernel; the alternative here is the generic sampler)
+    else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_fmin > 0.0f && d.xr >= d.area_direct_fmin &&
+             d.yr >= d.area_direct_fmin && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
+        d.area_direct = 2; // float weights
     else
         d.area_direct = 0;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
@@ -2377,7 +2419,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
             const bool sep = mode == M_BICUBIC && d.bicubic_sep && sh[1] >= 2;
-            const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx == 2 && d.ry == 2 && d.area2_pref;
+            const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx >= 2 && d.rx <= 3 && d.ry >= 2 && d.ry <= 3 && d.area2_pref;
             int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep || area2) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
@@ -2409,8 +2451,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
                         need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
                                 (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
-                    if (area2) // column / row tables of the 2x2 float AREA kernel
-                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(A2XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(A2YEntry);
+                    if (area2) // column / row tables and row bases of the float AREA kernel
+                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(AFXEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(AFYEntry) +
+                                sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv);
                     if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
                         need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(YEntry);
                     if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights (+ the H planes of the separable kernel)

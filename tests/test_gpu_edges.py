@@ -183,3 +183,37 @@ def test_area_dyadic_lds_kernel_ratios_2_to_3p5(vpp, oracle, src, dst):
     y, uv = synth_nv12(src[0], src[1], seed=src[0] * 3 + dst[1], pitch=src[0] + 6)
     conv(vpp, oracle, y, uv, width=src[0], dst=dst, rt=3, planes=0, norm=True)
     conv(vpp, oracle, y, uv, width=src[0], crop=(2, 2, src[0] - 2, src[1] - 2), dst=dst, rt=3, planes=1, norm=False)
+
+
+@pytest.mark.parametrize("fmin", [None, "3"])
+def test_area_float_kernel_up_to_3x3_taps(oracle, monkeypatch, fmin):
+    """Non-dyadic AREA with 2 or 3 taps per axis in every combination (3x2, 2x3, 3x3): the LDS float kernel; with
+    TSVPP_AREA_DIRECT_FMIN=3 also the 3x3 cases that the direct float kernel takes by default."""
+    import tensor_stream as ts
+    if fmin:
+        monkeypatch.setenv("TSVPP_AREA_DIRECT_FMIN", fmin)
+    v = ts.VideoProcessor(device=0, max_consumers=2)
+    try:
+        y, uv = synth_nv12(1080, 608, seed=99, pitch=1091)
+        for dst in [(480, 360), (640, 224), (452, 256), (400, 240), (364, 380)]:
+            conv(v, oracle, y, uv, width=1080, dst=dst, rt=3, planes=0, norm=True)
+            conv(v, oracle, y, uv, width=1080, crop=(1, 2, 1079, 606), dst=dst, rt=3, planes=1, norm=False)
+            conv(v, oracle, y, uv, width=1080, dst=dst, rt=3, fourcc=6, norm=True)
+    finally:
+        v.Close()
+
+
+@pytest.mark.parametrize("rt", RT)
+def test_widths_of_the_form_4k_plus_2_stay_on_the_fast_kernels(vpp, oracle, rt):
+    """854x480, 1366x768, ... : the last thread tile of every row has two columns.  It stores on the scalar path and
+    must neither read past the source rows nor disturb the merged-fp32 exchange of its wave."""
+    y, uv = synth_nv12(1366, 768, seed=31 + rt, pitch=1376)
+    for dst in [(854, 480), (682, 384), (1366, 768) if rt == 0 else (1370, 770), (342, 192), (170, 96), (2050, 1154)]:
+        conv(vpp, oracle, y, uv, width=1366, dst=dst, rt=rt, planes=0, norm=True)
+        conv(vpp, oracle, y, uv, width=1366, dst=dst, rt=rt, planes=1, norm=True)
+        conv(vpp, oracle, y, uv, width=1366, dst=dst, rt=rt, planes=1, norm=False)
+        conv(vpp, oracle, y, uv, width=1366, dst=dst, rt=rt, fourcc=3, norm=False)
+    # colour-only and crop-only with a 4 k + 2 wide source
+    conv(vpp, oracle, y, uv, width=1366, planes=0, norm=True)
+    conv(vpp, oracle, y, uv, width=1366, crop=(4, 2, 1362, 766), planes=0, norm=False)
+    conv(vpp, oracle, y, uv, width=1366, crop=(0, 0, 1362, 760), dst=(0, 0), fourcc=5, norm=True)
