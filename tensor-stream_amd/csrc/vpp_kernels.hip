@@ -1725,7 +1725,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int nthreads = d.tx * d.ty;
-    const int tw = d.tx * PXW, th = d.ty * PXH;
+    const int tw = d.tx * PXW, th = d.ty * PXH * d.rpt;
     const Footprint f = tile_footprint<M_AREA_DOWN>(d, id);
 
     uint8_t *lds_y = lds_raw;
@@ -1789,12 +1789,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     __syncthreads();
 
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-
+    const int j0 = f.j_first + lx * PXW;
+    if (j0 >= d.dst_w) return;
+    // thread tile = 4 columns x (2 * rpt) rows: tile decode, staging set-up and table build are paid once per 8 * rpt pixels
+    for (int rp = 0; rp < d.rpt; rp++) {
+    const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
+    if (i0 >= d.dst_h) break;
     float Uf[2], Vf[2], Yf[PXH][PXW];
     { // chroma: U on even bytes, V on odd bytes of the same dwords
-        const AYEntry ye = cytab[ly];
+        const AYEntry ye = cytab[lyr];
         uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
         ACEntry ce[2] = { cxtab[lx * 2], cxtab[lx * 2 + 1] };
 #pragma unroll
@@ -1829,7 +1832,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         for (int c = 0; c < PXW; c++) xe[c] = xtab[lx * PXW + c];
 #pragma unroll
         for (int r = 0; r < PXH; r++) {
-            const AYEntry ye = ytab[ly * PXH + r];
+            const AYEntry ye = ytab[lyr * PXH + r];
             uint32_t sum[PXW] = { 0, 0, 0, 0 };
 #pragma unroll
             for (int a = 0; a < ry; a++) {
@@ -1850,6 +1853,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2420,13 +2424,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             if (sh[0] == 0 || staged) break;
             const bool sep = mode == M_BICUBIC && d.bicubic_sep && sh[1] >= 2;
             const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx >= 2 && d.rx <= 3 && d.ry >= 2 && d.ry <= 3 && d.area2_pref;
-            int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep || area2) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
+            const bool dyadic = mode == M_AREA_DOWN && d.qx && d.qy;
+            int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep || area2 || dyadic) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
             while (rpt_max > 1 && workgroups(sh, rpt_max) < 16L * d.num_cus) rpt_max--;
             // separable BICUBIC: a taller tile that does not fit falls back to a shorter tile of the SAME workgroup
             // shape before a smaller workgroup is tried (measured: 1080p -> 640x640, 375 k vs 288 k frames/s)
-            for (int rpt = rpt_max; rpt >= 1 && !staged; rpt = sep ? rpt - 1 : 0) {
+            for (int rpt = rpt_max; rpt >= 1 && !staged; rpt = (sep || dyadic) ? rpt - 1 : 0) {
                 const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
                 const int rows_y = span_bound(mode, sh[1] * PXH * rpt, d.yr, d.ry);
                 const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
@@ -2450,7 +2455,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     size_t need = (size_t)16 * ((size_t)rows_alloc_y * cpr_y + (size_t)rows_alloc_uv * cpr_uv);
                     if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
                         need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
-                                (size_t)(sh[1] * PXH + sh[1] * PXH / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
+                                (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
                     if (area2) // column / row tables and row bases of the float AREA kernel
                         need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(AFXEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(AFYEntry) +
                                 sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv);
