@@ -429,16 +429,17 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
-    // vector-store kernels: 16-byte aligned outputs; dst_w is even, and when it is 4 k + 2 the last thread tile of a row
-    // stores its two columns on the scalar path (rows then start 8 bytes / 2 bytes off the vector alignment, which
-    // global stores tolerate)
-    bool vec = true;
+    // Every request runs on the vector-store kernels.  dst_w is even; when it is 4 k + 2 the last thread tile of a row
+    // stores its two columns element-wise (rows then start 8 bytes / 2 bytes off the vector alignment, which global
+    // stores tolerate); when an output pointer is not 16-byte aligned every thread does.
+    const bool vec = true;
+    bool aligned_out = true;
     for (int f = 0; f < n; f++) {
         if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
         if (in[f].width != in[0].width || in[f].height != in[0].height) return TSVPP_UNSUPPORTED;
         if ((in[f].pitch_y ? in[f].pitch_y : in[f].width) != pitch_y) return TSVPP_UNSUPPORTED;
         if ((in[f].pitch_uv ? in[f].pitch_uv : in[f].width) != pitch_uv) return TSVPP_UNSUPPORTED;
-        if (((uintptr_t)outs[f] & 15) != 0) vec = false;
+        if (((uintptr_t)outs[f] & 15) != 0) aligned_out = false;
     }
     sts = ensure_device(ctx);
     if (sts != TSVPP_OK) return sts;
@@ -468,6 +469,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     d.area_direct_min = ctx->area_direct_min;
     d.area_direct_fmin = ctx->area_direct_fmin;
     d.bicubic_sep = ctx->bicubic_sep;
+    d.scalar_stores = aligned_out ? 0 : 1;
     d.area2_pref = ctx->area2;
     d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
@@ -527,7 +529,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     }
     const OutKind out_kind = pl.out;
     if (two_pass) {
-        vec = true; // scratch frames are 256-byte aligned
+        d.scalar_stores = 0; // scratch frames are 256-byte aligned
         if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     }
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {

@@ -565,8 +565,8 @@ template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
                                                  typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
     if constexpr (VEC) { // dst_w = 4 k + 2: the row's last thread tile has two columns; it alone takes the scalar path
-        if (d.dst_w - j0 < PXW) {
-            color_store_tile<OUT, false>(Yf, Uf, Vf, d, out, i0, j0, d.dst_w - j0);
+        if (d.dst_w - j0 < PXW || d.scalar_stores) { // (or every thread, when an output is not 16-byte aligned)
+            color_store_tile<OUT, false>(Yf, Uf, Vf, d, out, i0, j0, min(PXW, d.dst_w - j0));
             return;
         }
     }
