@@ -18,10 +18,14 @@
  * Parity status: PINNED for the colour conversion (RGB24/BGR24/Y800/UYVY/YUV444/
  * HSV/NV12) against the reference's own fp32 golden files
  * (tests/resources/test_references/FOURCC_320x240.yuv; see tests/golden/).
- * NEAREST and crop are integer index math.  BILINEAR/BICUBIC/AREA at
- * non-dyadic weights are "parity unpinned" in this container (the only goldens
- * are CRCs of a decoded H.264 frame and no decoder exists here); they are
- * exact by construction at every BASELINE.json ratio.
+ * NEAREST and crop are integer index math.  NEAREST/BILINEAR/BICUBIC/AREA (down-
+ * and up-scale) are pinned by the reference's 16 PSNR known-answers
+ * (tests/src/VPPTests.cpp:673-911, +-0.01 dB) replayed on its own two JPEGs:
+ * all 16 reproduced within 0.010 dB (tests/test_reference_psnr.py).  That pin is
+ * statistical: the byte-exact goldens of the interpolating kernels are CRC-32s
+ * of a decoded H.264 frame and no decoder exists in this container ("parity
+ * unpinned" at the bit level for BILINEAR/BICUBIC/AREA at non-dyadic weights;
+ * they are exact by construction at every BASELINE.json ratio).
  *
  * Arithmetic conventions (see DESIGN.md "Arithmetic contract"):
  *   - every float expression is evaluated operation by operation, rounded to
