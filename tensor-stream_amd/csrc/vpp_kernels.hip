@@ -460,7 +460,8 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
         y.x = __builtin_fmaxf(0.0f, y.x);
         y.y = __builtin_fmaxf(0.0f, y.y);
         y = y * (f2){ k.y_scale, k.y_scale };
-        if constexpr (sizeof(T) == 1 && VEC) { // the saturating pack below clamps
+        if constexpr (sizeof(T) == 1) { // the saturating pack below clamps (same arithmetic on the vector and the element-wise path:
+                                        // the row-tail branch then shares every value with the main path instead of recomputing it)
             c0[p] = trunc2(y + (f2){ t0[p], t0[p] });
             c1[p] = trunc2(y + (f2){ tg[p], tg[p] });
             c2[p] = trunc2(y + (f2){ t2[p], t2[p] });
@@ -542,18 +543,18 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                 st1o(o, 3u * pix + 8u, pack_u8x4(c2[1].x, c0[1].y, c1[1].y, c2[1].y), nt);
             }
         } else {
-            const uint8_t v0[4] = { (uint8_t)(int)c0[0].x, (uint8_t)(int)c0[0].y, (uint8_t)(int)c0[1].x, (uint8_t)(int)c0[1].y };
-            const uint8_t v1[4] = { (uint8_t)(int)c1[0].x, (uint8_t)(int)c1[0].y, (uint8_t)(int)c1[1].x, (uint8_t)(int)c1[1].y };
-            const uint8_t v2[4] = { (uint8_t)(int)c2[0].x, (uint8_t)(int)c2[0].y, (uint8_t)(int)c2[1].x, (uint8_t)(int)c2[1].y };
+            const uint32_t p0 = pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), p1 = pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y),
+                           p2 = pack_u8x4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
             for (int c = 0; c < ncol; c++) {
+                const uint8_t v0 = (uint8_t)(p0 >> (8 * c)), v1 = (uint8_t)(p1 >> (8 * c)), v2 = (uint8_t)(p2 >> (8 * c));
                 if constexpr (PLANAR) {
-                    o[pix + c] = v0[c];
-                    o[plane + pix + c] = v1[c];
-                    o[2 * plane + pix + c] = v2[c];
+                    o[pix + c] = v0;
+                    o[plane + pix + c] = v1;
+                    o[2 * plane + pix + c] = v2;
                 } else {
-                    o[3 * (pix + c)] = v0[c];
-                    o[3 * (pix + c) + 1] = v1[c];
-                    o[3 * (pix + c) + 2] = v2[c];
+                    o[3 * (pix + c)] = v0;
+                    o[3 * (pix + c) + 1] = v1;
+                    o[3 * (pix + c) + 2] = v2;
                 }
             }
         }
