@@ -130,6 +130,14 @@ void tsvpp_default_coeffs(tsvpp_coeffs *out);
  * (taps = ceil(scale)) to `out` if it fits `max_floats`; returns rows or <0. */
 int tsvpp_area_pattern(float scale, float *out, int max_floats, int *taps);
 
+/* What tsvpp_convert_batch WOULD launch for this request -- stage selection (reference
+ * src/VideoProcessor.cpp:106-151) plus this library's kernel / workgroup-shape / LDS choice -- as one line of
+ * key=value text, e.g. "mode=bilinear out=f32_planar ... kernel=vpp_bilinear_kernel<...> shape=32x8 rpt=2 ...".
+ * Needs no context and no GPU (host logic only; TSVPP_* knobs are honoured).  `aligned_outputs`: outputs are 16-byte
+ * aligned.  Returns TSVPP_OK or the status tsvpp_convert would return for the request. */
+int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch_y, int pitch_uv, int n_frames, int aligned_outputs, char *buf,
+                   size_t buf_len);
+
 /* Human-readable text for a status returned by this library. */
 const char *tsvpp_strerror(int status);
 /* "tsvpp <version> gfx950" */

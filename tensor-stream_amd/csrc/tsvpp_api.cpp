@@ -234,6 +234,58 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     return TSVPP_OK;
 }
 
+// Tuning knobs (profiling / A-B only), read once per context.
+void read_env_knobs(tsvpp_ctx *ctx) {
+    if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
+    if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = std::atoi(e); // 0 plain, 1 nt, 2 sc1; default -1 = per kernel
+    if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
+    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
+}
+
+// The part of the launch descriptor that depends only on the request and the knobs.
+void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, LaunchDesc &d) {
+    std::memset(&d, 0, sizeof(d));
+    d.src_w = pl.src_w;
+    d.src_h = pl.src_h;
+    d.pitch_y = pitch_y;
+    d.pitch_uv = pitch_uv;
+    d.dst_w = pl.dst_w;
+    d.dst_h = pl.dst_h;
+    d.xr = pl.xr;
+    d.yr = pl.yr;
+    d.swap_rb = pl.swap_rb;
+    d.point_kind = pl.point_kind;
+    d.k = ctx->coeffs;
+    d.force_gather = ctx->force_gather;
+    d.nt_stores = ctx->nt_stores;
+    d.tile_order = ctx->tile_order;
+    d.shape_tx = ctx->shape_tx;
+    d.shape_ty = ctx->shape_ty;
+    d.ablate = ctx->ablate;
+    d.persist = ctx->persist;
+    d.dma = ctx->dma;
+    d.rpt_pref = ctx->rpt;
+    d.area_direct_min = ctx->area_direct_min;
+    d.area_direct_fmin = ctx->area_direct_fmin;
+    d.bicubic_sep = ctx->bicubic_sep;
+    d.area2_pref = ctx->area2;
+    d.num_cus = ctx->num_cus;
+}
+
+// Integer box sums are exact (and equal to the reference's float accumulation) while 255 * sum(wx) * sum(wy) stays
+// below 2^24; one divisor for the whole frame allows an exact integer division by a constant in the kernel.
+bool dyadic_usable(float xr, float yr, int shift_x, int shift_y) {
+    return (double)255 * ((double)xr * (1 << shift_x) + 1) * ((double)yr * (1 << shift_y) + 1) < 16777216.0;
+}
+
 int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     uint32_t key;
     std::memcpy(&key, &scale, 4);
@@ -320,22 +372,11 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     tsvpp_ctx *ctx = new tsvpp_ctx();
     ctx->device = device;
     tsvpp_default_coeffs(&ctx->coeffs);
-    if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
-    if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = std::atoi(e); // 0 plain, 1 nt, 2 sc1; default -1 = per kernel
-    if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
-    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
-    if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
+    read_env_knobs(ctx);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
     }
-    if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
     for (int i = 0; i < max_consumers; i++) {
         hipStream_t s = nullptr;
         e = hipStreamCreate(&s); // blocking stream, as the reference (src/VideoProcessor.cpp:86)
@@ -445,33 +486,8 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     if (sts != TSVPP_OK) return sts;
 
     LaunchDesc d;
-    std::memset(&d, 0, sizeof(d));
-    d.src_w = pl.src_w;
-    d.src_h = pl.src_h;
-    d.pitch_y = pitch_y;
-    d.pitch_uv = pitch_uv;
-    d.dst_w = pl.dst_w;
-    d.dst_h = pl.dst_h;
-    d.xr = pl.xr;
-    d.yr = pl.yr;
-    d.swap_rb = pl.swap_rb;
-    d.point_kind = pl.point_kind;
-    d.k = ctx->coeffs;
-    d.force_gather = ctx->force_gather;
-    d.nt_stores = ctx->nt_stores;
-    d.tile_order = ctx->tile_order;
-    d.shape_tx = ctx->shape_tx;
-    d.shape_ty = ctx->shape_ty;
-    d.ablate = ctx->ablate;
-    d.persist = ctx->persist;
-    d.dma = ctx->dma;
-    d.rpt_pref = ctx->rpt;
-    d.area_direct_min = ctx->area_direct_min;
-    d.area_direct_fmin = ctx->area_direct_fmin;
-    d.bicubic_sep = ctx->bicubic_sep;
+    fill_desc(ctx, pl, pitch_y, pitch_uv, d);
     d.scalar_stores = aligned_out ? 0 : 1;
-    d.area2_pref = ctx->area2;
-    d.num_cus = ctx->num_cus;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;
         sts = get_area_table(ctx, pl.xr, tx);
@@ -488,9 +504,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.nkx = tx.nk;
         d.paty4 = ty.dev4;
         d.nky = ty.nk;
-        // integer box sums are exact (and equal to the reference's float accumulation) while
-        // 255 * sum(wx) * sum(wy) stays below 2^24
-        if (tx.qdev && ty.qdev && (double)255 * ((double)pl.xr * (1 << tx.shift) + 1) * ((double)pl.yr * (1 << ty.shift) + 1) < 16777216.0) {
+        if (tx.qdev && ty.qdev && dyadic_usable(pl.xr, pl.yr, tx.shift, ty.shift)) {
             d.qx = tx.qdev;
             d.qy = ty.qdev;
             // one divisor for the whole frame -> exact integer division by a constant in the kernel
@@ -591,6 +605,77 @@ int tsvpp_area_pattern(float scale, float *out, int max_floats, int *taps) {
     if (taps) *taps = t;
     if (out && (long)tab.size() <= (long)max_floats) std::memcpy(out, tab.data(), tab.size() * sizeof(float));
     return rows;
+}
+
+int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch_y, int pitch_uv, int n_frames, int aligned_outputs, char *buf,
+                   size_t buf_len) {
+    if (!p || !buf || buf_len == 0) return TSVPP_ERROR;
+    buf[0] = 0;
+    Plan pl;
+    int sts = make_plan(p, in_width, in_height, pl);
+    if (sts != TSVPP_OK) return sts;
+    if (pitch_y == 0) pitch_y = in_width;
+    if (pitch_uv == 0) pitch_uv = in_width;
+    if (pitch_y < in_width || pitch_uv < in_width || n_frames < 1) return TSVPP_ERROR;
+    tsvpp_ctx tmp; // knobs only: no device, no streams
+    tsvpp_default_coeffs(&tmp.coeffs);
+    read_env_knobs(&tmp);
+    LaunchDesc d;
+    fill_desc(&tmp, pl, pitch_y, pitch_uv, d);
+    d.scalar_stores = aligned_outputs ? 0 : 1;
+    // frame pointers are assumed 256-byte aligned; the crop origin decides the rest
+    d.in_aligned4 = (pitch_y % 4 == 0 && pitch_uv % 4 == 0 && ((size_t)pl.off_y * pitch_y + pl.off_x) % 4 == 0 &&
+                     ((size_t)(pl.off_y / 2) * pitch_uv + pl.off_x) % 4 == 0)
+                        ? 1
+                        : 0;
+    static const float dummy_f[4] = { 0, 0, 0, 0 };
+    static const AreaQRow dummy_q = {};
+    if (pl.mode == M_AREA_DOWN) { // the same table properties get_area_table derives, without touching a device
+        int shift[2] = { -1, -1 }, uniform[2] = { 0, 0 };
+        bool dyadic[2] = { false, false };
+        for (int axis = 0; axis < 2; axis++) {
+            std::vector<float> tab;
+            int rows = 0, taps = 0;
+            if (!build_area_rows(axis ? pl.yr : pl.xr, tab, rows, taps)) return TSVPP_UNSUPPORTED;
+            std::vector<AreaQRow> q;
+            dyadic[axis] = quantise_area_rows(tab, rows, taps, q, shift[axis]);
+            if (dyadic[axis]) {
+                uniform[axis] = q[0].sum;
+                for (const AreaQRow &e : q)
+                    if (e.sum != q[0].sum) uniform[axis] = 0;
+            }
+            (axis ? d.ny : d.nx) = rows;
+            (axis ? d.ry : d.rx) = taps;
+            (axis ? d.nky : d.nkx) = (taps + 3) / 4;
+        }
+        d.patx = d.paty = d.patx4 = d.paty4 = dummy_f;
+        if (dyadic[0] && dyadic[1] && dyadic_usable(pl.xr, pl.yr, shift[0], shift[1])) {
+            d.qx = d.qy = &dummy_q;
+            if (uniform[0] > 0 && uniform[1] > 0 && (long)uniform[0] * uniform[1] < 4096) d.area_rcp = 1.0f / (float)(uniform[0] * uniform[1]);
+        }
+    }
+    const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
+    if (two_pass) d.scalar_stores = 0;
+    d.n_frames = n_frames < TSVPP_MAX_BATCH ? n_frames : TSVPP_MAX_BATCH;
+    static const char *const out_names[O_COUNT] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32" };
+    static const char *const mode_names[M_COUNT] = { "none", "nearest", "bilinear", "bicubic", "area_down", "area_up" };
+    LaunchInfo info = {};
+    info.kernel = "(none)";
+    if (!(two_pass && pl.mode == M_NONE)) {
+        FrameTable t = {};
+        hipError_t e = launch_fused(pl.mode, pl.out, true, d, t, nullptr, &info);
+        if (e != hipSuccess) return (int)e;
+    }
+    char kname[128]; // the launcher's spelling without blanks: one token per key=value pair
+    size_t kn = 0;
+    for (const char *c = info.kernel; *c && kn + 1 < sizeof(kname); c++)
+        if (*c != ' ') kname[kn++] = *c;
+    kname[kn] = 0;
+    std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d%s",
+                  mode_names[pl.mode], out_names[pl.out], pl.src_w, pl.src_h, pl.dst_w, pl.dst_h, kname, info.tx, info.ty, info.rpt, info.dma,
+                  info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames,
+                  two_pass ? (pl.fourcc == TSVPP_UYVY ? " pass2=fmt_uyvy" : " pass2=fmt_yuv444") : "");
+    return TSVPP_OK;
 }
 
 const char *tsvpp_strerror(int status) {

@@ -85,10 +85,17 @@ struct LaunchDesc {
 // (:95-105).  O_HSV_F32: merged HSV of the normalised RGB (:235-278).  The fp32 flavours are /255.
 enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_NV12_F32, O_Y800_U8, O_Y800_F32, O_HSV_F32, O_COUNT };
 
+// What launch_fused chose (dry run, see tsvpp_describe).
+struct LaunchInfo {
+    const char *kernel;
+    int tx, ty, rpt, dma, staged, lds_bytes, grid, tiles_x, tiles_y;
+};
+
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
 // store path (needs 16-byte aligned outputs; a row's last thread tile stores scalar when dst_w = 4 k + 2).
 // Returns hipError_t.
-hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream);
+// `info` != nullptr: a dry run -- the selection is recorded there and nothing is launched.
+hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info = nullptr);
 
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);
 // t.y / t.uv are the (resized or cropped) NV12 planes, t.out the outputs.

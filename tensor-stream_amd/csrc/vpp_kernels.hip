@@ -2245,23 +2245,36 @@ static int slot_shift_for(int cpr) {
     return s;
 }
 
+// Launch, or -- when the caller only wants to know what WOULD run (tsvpp_describe, CPU tests of the selection
+// logic) -- record the choice and launch nothing.
+#define TSVPP_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS)                                   \
+    do {                                                                               \
+        if (info) {                                                                    \
+            info->kernel = NAME;                                                       \
+            info->grid = (int)(GRID).x;                                                \
+            info->lds_bytes = (int)(LDS);                                              \
+        } else {                                                                       \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, stream, d, t);                \
+        }                                                                              \
+    } while (0)
+
 template <int OUT>
-static hipError_t launch_point(const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_point(const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     switch (d.point_kind) {
-    case PK_NEAREST: hipLaunchKernelGGL((vpp_point_kernel<PK_NEAREST, OUT>), grid, block, lds_bytes, stream, d, t); break;
-    case PK_BILINEAR0: hipLaunchKernelGGL((vpp_point_kernel<PK_BILINEAR0, OUT>), grid, block, lds_bytes, stream, d, t); break;
-    case PK_BICUBIC0: hipLaunchKernelGGL((vpp_point_kernel<PK_BICUBIC0, OUT>), grid, block, lds_bytes, stream, d, t); break;
+    case PK_NEAREST: TSVPP_LAUNCH("vpp_point_kernel<PK_NEAREST, OUT>", (vpp_point_kernel<PK_NEAREST, OUT>), grid, block, lds_bytes); break;
+    case PK_BILINEAR0: TSVPP_LAUNCH("vpp_point_kernel<PK_BILINEAR0, OUT>", (vpp_point_kernel<PK_BILINEAR0, OUT>), grid, block, lds_bytes); break;
+    case PK_BICUBIC0: TSVPP_LAUNCH("vpp_point_kernel<PK_BICUBIC0, OUT>", (vpp_point_kernel<PK_BICUBIC0, OUT>), grid, block, lds_bytes); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return info ? hipSuccess : hipGetLastError();
 }
 
 template <int MODE, int OUT>
-static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
-        return launch_point<OUT>(d, t, lds_bytes, stream);
+        return launch_point<OUT>(d, t, lds_bytes, stream, info);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
             // persistent variant: two LDS tile sets filled by LDS-DMA
@@ -2269,85 +2282,85 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
                 const long resident = (long)d.num_cus * d.persist;
                 dim3 pgrid((unsigned)(total < resident ? total : resident));
-                hipLaunchKernelGGL((vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, 2 * lds_bytes, stream, d, t);
-                return hipGetLastError();
+                TSVPP_LAUNCH("vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>", (vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, 2 * lds_bytes);
+                return info ? hipSuccess : hipGetLastError();
             }
-            hipLaunchKernelGGL((vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes, stream, d, t);
-            return hipGetLastError();
+            TSVPP_LAUNCH("vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>", (vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes);
+            return info ? hipSuccess : hipGetLastError();
         }
     } else if constexpr (MODE == M_BICUBIC) {
         if (staged) {
-            if (d.bicubic_sep) hipLaunchKernelGGL((vpp_bicubic_sep_kernel<OUT>), grid, block, lds_bytes, stream, d, t);
-            else hipLaunchKernelGGL((vpp_bicubic_kernel<OUT>), grid, block, lds_bytes, stream, d, t);
-            return hipGetLastError();
+            if (d.bicubic_sep) TSVPP_LAUNCH("vpp_bicubic_sep_kernel<OUT>", (vpp_bicubic_sep_kernel<OUT>), grid, block, lds_bytes);
+            else TSVPP_LAUNCH("vpp_bicubic_kernel<OUT>", (vpp_bicubic_kernel<OUT>), grid, block, lds_bytes);
+            return info ? hipSuccess : hipGetLastError();
         }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
             if (vec && d.area_direct == 1 && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
-                if (d.rx <= 4) hipLaunchKernelGGL((vpp_area_direct_kernel<1, OUT>), grid, block, 0, stream, d, t);
-                else hipLaunchKernelGGL((vpp_area_direct_kernel<2, OUT>), grid, block, 0, stream, d, t);
-                return hipGetLastError();
+                if (d.rx <= 4) TSVPP_LAUNCH("vpp_area_direct_kernel<1, OUT>", (vpp_area_direct_kernel<1, OUT>), grid, block, 0);
+                else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
+                return info ? hipSuccess : hipGetLastError();
             }
             if (vec && d.area_direct == 2 && !d.force_gather) { // large non-dyadic ratios: float sums straight from global memory
-                if (d.nkx == 1) hipLaunchKernelGGL((vpp_area_direct_float_kernel<1, OUT>), grid, block, 0, stream, d, t);
-                else if (d.nkx == 2) hipLaunchKernelGGL((vpp_area_direct_float_kernel<2, OUT>), grid, block, 0, stream, d, t);
-                else hipLaunchKernelGGL((vpp_area_direct_float_kernel<3, OUT>), grid, block, 0, stream, d, t);
-                return hipGetLastError();
+                if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_direct_float_kernel<1, OUT>", (vpp_area_direct_float_kernel<1, OUT>), grid, block, 0);
+                else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_direct_float_kernel<2, OUT>", (vpp_area_direct_float_kernel<2, OUT>), grid, block, 0);
+                else TSVPP_LAUNCH("vpp_area_direct_float_kernel<3, OUT>", (vpp_area_direct_float_kernel<3, OUT>), grid, block, 0);
+                return info ? hipSuccess : hipGetLastError();
             }
             if (staged && d.qx && d.qy) {
                 if (d.rx <= 4) {
-                    if (d.ry == 2) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 2, OUT>), grid, block, lds_bytes, stream, d, t);
-                    else if (d.ry == 3) hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 3, OUT>), grid, block, lds_bytes, stream, d, t);
-                    else hipLaunchKernelGGL((vpp_area_dyadic_kernel<1, 0, OUT>), grid, block, lds_bytes, stream, d, t);
+                    if (d.ry == 2) TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 2, OUT>", (vpp_area_dyadic_kernel<1, 2, OUT>), grid, block, lds_bytes);
+                    else if (d.ry == 3) TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 3, OUT>", (vpp_area_dyadic_kernel<1, 3, OUT>), grid, block, lds_bytes);
+                    else TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 0, OUT>", (vpp_area_dyadic_kernel<1, 0, OUT>), grid, block, lds_bytes);
                 } else {
-                    hipLaunchKernelGGL((vpp_area_dyadic_kernel<2, 0, OUT>), grid, block, lds_bytes, stream, d, t);
+                    TSVPP_LAUNCH("vpp_area_dyadic_kernel<2, 0, OUT>", (vpp_area_dyadic_kernel<2, 0, OUT>), grid, block, lds_bytes);
                 }
-                return hipGetLastError();
+                return info ? hipSuccess : hipGetLastError();
             }
         }
         if constexpr (MODE == M_AREA_DOWN) {
             if (staged && d.area2) { // float weights, at most 3 x 3 taps
-                if (d.rx == 2 && d.ry == 2) hipLaunchKernelGGL((vpp_areaf_kernel<2, 2, OUT>), grid, block, lds_bytes, stream, d, t);
-                else if (d.rx == 3 && d.ry == 2) hipLaunchKernelGGL((vpp_areaf_kernel<3, 2, OUT>), grid, block, lds_bytes, stream, d, t);
-                else if (d.rx == 2 && d.ry == 3) hipLaunchKernelGGL((vpp_areaf_kernel<2, 3, OUT>), grid, block, lds_bytes, stream, d, t);
-                else hipLaunchKernelGGL((vpp_areaf_kernel<3, 3, OUT>), grid, block, lds_bytes, stream, d, t);
-                return hipGetLastError();
+                if (d.rx == 2 && d.ry == 2) TSVPP_LAUNCH("vpp_areaf_kernel<2, 2, OUT>", (vpp_areaf_kernel<2, 2, OUT>), grid, block, lds_bytes);
+                else if (d.rx == 3 && d.ry == 2) TSVPP_LAUNCH("vpp_areaf_kernel<3, 2, OUT>", (vpp_areaf_kernel<3, 2, OUT>), grid, block, lds_bytes);
+                else if (d.rx == 2 && d.ry == 3) TSVPP_LAUNCH("vpp_areaf_kernel<2, 3, OUT>", (vpp_areaf_kernel<2, 3, OUT>), grid, block, lds_bytes);
+                else TSVPP_LAUNCH("vpp_areaf_kernel<3, 3, OUT>", (vpp_areaf_kernel<3, 3, OUT>), grid, block, lds_bytes);
+                return info ? hipSuccess : hipGetLastError();
             }
         }
         if (staged) {
-            hipLaunchKernelGGL((vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes, stream, d, t);
-            return hipGetLastError();
+            TSVPP_LAUNCH("vpp_fused_staged_kernel<MODE, OUT>", (vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes);
+            return info ? hipSuccess : hipGetLastError();
         }
     } else {
         if (staged) { // colour-only fast path ("staged" = eligible)
-            hipLaunchKernelGGL((vpp_color_kernel<OUT>), grid, block, 0, stream, d, t);
-            return hipGetLastError();
+            TSVPP_LAUNCH("vpp_color_kernel<OUT>", (vpp_color_kernel<OUT>), grid, block, 0);
+            return info ? hipSuccess : hipGetLastError();
         }
     }
     if (vec)
-        hipLaunchKernelGGL((vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0, stream, d, t);
+        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
     else
-        hipLaunchKernelGGL((vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0, stream, d, t);
-    return hipGetLastError();
+        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, false>", (vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0);
+    return info ? hipSuccess : hipGetLastError();
 }
 
 template <int MODE>
-static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds, hipStream_t stream) {
+static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds, hipStream_t stream, LaunchInfo *info) {
     switch (out) {
-    case O_U8_PLANAR: return launch_mo<MODE, O_U8_PLANAR>(vec, staged, d, t, lds, stream);
-    case O_U8_MERGED: return launch_mo<MODE, O_U8_MERGED>(vec, staged, d, t, lds, stream);
-    case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, staged, d, t, lds, stream);
-    case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, staged, d, t, lds, stream);
-    case O_NV12_U8: return launch_mo<MODE, O_NV12_U8>(vec, staged, d, t, lds, stream);
-    case O_NV12_F32: return launch_mo<MODE, O_NV12_F32>(vec, staged, d, t, lds, stream);
-    case O_Y800_U8: return launch_mo<MODE, O_Y800_U8>(vec, staged, d, t, lds, stream);
-    case O_Y800_F32: return launch_mo<MODE, O_Y800_F32>(vec, staged, d, t, lds, stream);
-    case O_HSV_F32: return launch_mo<MODE, O_HSV_F32>(vec, staged, d, t, lds, stream);
+    case O_U8_PLANAR: return launch_mo<MODE, O_U8_PLANAR>(vec, staged, d, t, lds, stream, info);
+    case O_U8_MERGED: return launch_mo<MODE, O_U8_MERGED>(vec, staged, d, t, lds, stream, info);
+    case O_F32_PLANAR: return launch_mo<MODE, O_F32_PLANAR>(vec, staged, d, t, lds, stream, info);
+    case O_F32_MERGED: return launch_mo<MODE, O_F32_MERGED>(vec, staged, d, t, lds, stream, info);
+    case O_NV12_U8: return launch_mo<MODE, O_NV12_U8>(vec, staged, d, t, lds, stream, info);
+    case O_NV12_F32: return launch_mo<MODE, O_NV12_F32>(vec, staged, d, t, lds, stream, info);
+    case O_Y800_U8: return launch_mo<MODE, O_Y800_U8>(vec, staged, d, t, lds, stream, info);
+    case O_Y800_F32: return launch_mo<MODE, O_Y800_F32>(vec, staged, d, t, lds, stream, info);
+    case O_HSV_F32: return launch_mo<MODE, O_HSV_F32>(vec, staged, d, t, lds, stream, info);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream) {
+hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
     LaunchDesc d = din;
     d.rpt = 1;
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
@@ -2429,7 +2442,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             int rpt_max = (((mode == M_BILINEAR || mode == M_AREA_UP) && !d.persist) || sep || area2 || dyadic) && d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
-            while (rpt_max > 1 && workgroups(sh, rpt_max) < 16L * d.num_cus) rpt_max--;
+            // (the 2x2-tap kernel wants six rounds: measured cross-over between 8704 workgroups -- 1080p -> 960x540, two-row
+            // tiles 7 % faster -- and 14720 -- the headline, four-row tiles 3-7 % faster)
+            const long rounds = (mode == M_BILINEAR || mode == M_AREA_UP) ? 48L : 16L;
+            while (rpt_max > 1 && workgroups(sh, rpt_max) < rounds * d.num_cus) rpt_max--;
             // separable BICUBIC: a taller tile that does not fit falls back to a shorter tile of the SAME workgroup
             // shape before a smaller workgroup is tried (measured: 1080p -> 640x640, 375 k vs 288 k frames/s)
             for (int rpt = rpt_max; rpt >= 1 && !staged; rpt = (sep || dyadic) ? rpt - 1 : 0) {
@@ -2499,13 +2515,22 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const long rows = (long)d.tiles_y * d.n_frames;
         d.blocks_per_xcd = (int)(((rows + NUM_XCD - 1) / NUM_XCD) * d.tiles_x);
     }
+    if (info) {
+        info->tx = d.tx;
+        info->ty = d.ty;
+        info->rpt = d.rpt;
+        info->dma = d.dma;
+        info->staged = staged ? 1 : 0;
+        info->tiles_x = d.tiles_x;
+        info->tiles_y = d.tiles_y;
+    }
     switch (mode) {
-    case M_NONE: return launch_m<M_NONE>(out, vec, staged, d, t, lds_bytes, stream);
-    case M_NEAREST: return launch_m<M_NEAREST>(out, vec, staged, d, t, lds_bytes, stream);
-    case M_BILINEAR: return launch_m<M_BILINEAR>(out, vec, staged, d, t, lds_bytes, stream);
-    case M_BICUBIC: return launch_m<M_BICUBIC>(out, vec, staged, d, t, lds_bytes, stream);
-    case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, vec, staged, d, t, lds_bytes, stream);
-    case M_AREA_UP: return launch_m<M_AREA_UP>(out, vec, staged, d, t, lds_bytes, stream);
+    case M_NONE: return launch_m<M_NONE>(out, vec, staged, d, t, lds_bytes, stream, info);
+    case M_NEAREST: return launch_m<M_NEAREST>(out, vec, staged, d, t, lds_bytes, stream, info);
+    case M_BILINEAR: return launch_m<M_BILINEAR>(out, vec, staged, d, t, lds_bytes, stream, info);
+    case M_BICUBIC: return launch_m<M_BICUBIC>(out, vec, staged, d, t, lds_bytes, stream, info);
+    case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, vec, staged, d, t, lds_bytes, stream, info);
+    case M_AREA_UP: return launch_m<M_AREA_UP>(out, vec, staged, d, t, lds_bytes, stream, info);
     default: return hipErrorInvalidValue;
     }
 }

@@ -35,7 +35,7 @@ class Coeffs(ctypes.Structure):
 # every symbol include/tsvpp.h declares (tests check that the library exports all of them)
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
            "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_get_coeffs",
-           "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_strerror", "tsvpp_version"]
+           "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version"]
 
 _lib = None
 
@@ -68,12 +68,13 @@ def lib():
     L.tsvpp_default_coeffs.argtypes = [ctypes.POINTER(Coeffs)]
     L.tsvpp_default_coeffs.restype = None
     L.tsvpp_area_pattern.argtypes = [ctypes.c_float, vp, i32, ctypes.POINTER(i32)]
+    L.tsvpp_describe.argtypes = [pp, i32, i32, i32, i32, i32, i32, ctypes.c_char_p, ctypes.c_size_t]
     L.tsvpp_strerror.argtypes = [i32]
     L.tsvpp_strerror.restype = ctypes.c_char_p
     L.tsvpp_version.argtypes = []
     L.tsvpp_version.restype = ctypes.c_char_p
     for f in ("tsvpp_create", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_convert", "tsvpp_convert_batch",
-              "tsvpp_prepare", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern"):
+              "tsvpp_prepare", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern", "tsvpp_describe"):
         getattr(L, f).restype = i32
     _lib = L
     return L

@@ -193,6 +193,19 @@ class VideoProcessor:
         N.check(self._lib.tsvpp_set_coeffs(self._ctx, ctypes.byref(c)))
 
 
+def describe(params, in_w, in_h, pitch=0, n_frames=64, aligned_outputs=True):
+    """What a convert_batch of this request would launch (stage selection, kernel, workgroup shape, LDS bytes, grid)
+    as a dict -- host logic only, works without a GPU (tsvpp_describe)."""
+    p = params.parameters if isinstance(params, FrameParameters) else params
+    buf = ctypes.create_string_buffer(512)
+    N.check(N.lib().tsvpp_describe(ctypes.byref(p), in_w, in_h, pitch, pitch, n_frames, 1 if aligned_outputs else 0, buf, len(buf)))
+    out = {}
+    for item in buf.value.decode().split(" "):
+        k, _, v = item.partition("=")
+        out[k] = int(v) if v.lstrip("-").isdigit() else v
+    return out
+
+
 def default_coeffs():
     c = N.Coeffs()
     N.lib().tsvpp_default_coeffs(ctypes.byref(c))

@@ -1,0 +1,96 @@
+"""CPU: the host-side selection logic of the HIP path -- which kernel, workgroup shape, row pairs per thread and
+LDS budget a request gets -- through tsvpp_describe (a dry run of launch_fused: nothing is launched, no GPU needed).
+Guards the measured heuristics against silent regressions."""
+import pytest
+
+import tensor_stream as ts
+
+N, B, C, A = 0, 1, 2, 3
+Y800, RGB24, BGR24, NV12, UYVY, YUV444, HSV = range(7)
+
+
+def plan(src, dst=(0, 0), rt=N, fourcc=BGR24, planes=0, norm=True, crop=(0, 0, 0, 0), pitch=0, **kw):
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes,
+                            normalization=norm)
+    return ts.describe(fp, src[0], src[1], pitch=pitch, **kw)
+
+
+def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
+    p = plan((1920, 1080), (1280, 720), B, pitch=2048)
+    assert p["mode"] == "bilinear" and p["out"] == "f32_planar"
+    assert p["kernel"].startswith("vpp_bilinear_kernel<") and (p["shape"], p["rpt"], p["dma"]) == ("32x8", 2, 1)
+    assert p["tiles"] == "10x23" and p["frames"] == 64 and p["lds"] <= 40 * 1024
+    # whole tile rows per XCD: rows padded to a multiple of 8
+    assert p["grid"] == (23 * 64 + 7) // 8 * 8 * 10
+
+
+@pytest.mark.parametrize("src,dst,rt,kernel", [
+    ((1920, 1080), (0, 0), N, "vpp_color_kernel"),                       # C2: no resize
+    ((3840, 2160), (1280, 720), C, "vpp_point_kernel<PK_BICUBIC0"),      # C4: every cubic weight is zero
+    ((3840, 2160), (1280, 720), B, "vpp_point_kernel<PK_BILINEAR0"),
+    ((1920, 1080), (1280, 720), N, "vpp_point_kernel<PK_NEAREST"),
+    ((3840, 2160), (640, 360), A, "vpp_area_direct_kernel<2"),           # C5: 6 x 6 integer box sums from global memory
+    ((3840, 2160), (960, 540), A, "vpp_area_direct_kernel<1"),           # 4 x 4
+    ((1920, 1080), (1280, 720), A, "vpp_area_dyadic_kernel<1,2"),       # 1.5: dyadic weights, LDS
+    ((1920, 1080), (960, 540), A, "vpp_area_dyadic_kernel<1,2"),        # 2: LDS kernel below 3.5
+    ((1920, 1080), (640, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 3
+    ((2560, 1440), (1920, 1080), A, "vpp_areaf_kernel<2,2"),            # 4/3: float weights, 2 x 2 taps
+    ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
+    ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
+    ((1920, 1080), (224, 224), A, "vpp_area_direct_float_kernel<3"),     # 8.57 x 4.82
+    ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<MODE==M_AREA_UP"),  # AREA up-scale = the bilinear variant
+    ((1920, 1080), (1280, 720), C, "vpp_bicubic_sep_kernel"),
+    ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
+    ((1920, 1080), (224, 224), C, "vpp_fused_gather_kernel"),
+])
+def test_kernel_families(src, dst, rt, kernel):
+    p = plan(src, dst, rt)
+    assert p["kernel"].startswith(kernel), p
+
+
+def test_c3_crop_folds_into_pointers_and_the_sparse_bilinear_gathers():
+    p = plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=2048)
+    assert (p["src"], p["dst"]) == ("1280x720", "256x256") and p["kernel"].startswith("vpp_fused_gather_kernel")
+
+
+def test_small_outputs_keep_two_row_thread_tiles():
+    # 48 * num_cus workgroups are needed before the 4-row thread tile pays in the 2x2-tap kernel (16 in the others)
+    assert plan((1920, 1080), (1280, 720), B, n_frames=8)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
+    assert plan((1920, 1080), (1280, 720), B, n_frames=64)["rpt"] == 2   # 14720 >= 12288
+    assert plan((1920, 1080), (960, 540), B, n_frames=64)["rpt"] == 1    # 8704: measured 7 % faster with two-row tiles
+    assert plan((3840, 2160), (1920, 1080), B, n_frames=64)["rpt"] == 2
+    assert plan((1920, 1080), (960, 540), A, n_frames=64)["rpt"] == 2    # dyadic AREA: four-row tiles from 4096 workgroups
+
+
+def test_output_flavours_share_the_sampling_kernels():
+    for fourcc, out in [(Y800, "y800_f32"), (NV12, "nv12_f32"), (HSV, "hsv_f32"), (RGB24, "f32_planar")]:
+        p = plan((1920, 1080), (1280, 720), B, fourcc=fourcc)
+        assert p["out"] == out and p["kernel"].startswith("vpp_bilinear_kernel<")
+    assert plan((1920, 1080), (1280, 720), B, fourcc=Y800, norm=False)["out"] == "y800_u8"
+    p = plan((1920, 1080), (1280, 720), B, fourcc=UYVY)
+    assert p["out"] == "nv12_u8" and p["pass2"] == "fmt_uyvy"            # two passes: resized NV12, then the format kernel
+    p = plan((1920, 1080), (0, 0), N, fourcc=YUV444)
+    assert p["kernel"] == "(none)" and p["pass2"] == "fmt_yuv444"        # no resize: the format kernel reads the input itself
+
+
+def test_widths_4k_plus_2_and_unaligned_outputs_stay_on_the_fast_kernels():
+    assert plan((1920, 1080), (854, 480), A)["kernel"].startswith("vpp_area_direct_float_kernel<1")
+    assert plan((1920, 1080), (1366, 768), A)["kernel"].startswith("vpp_areaf_kernel<2,2")
+    assert plan((1920, 1080), (854, 480), B)["kernel"].startswith("vpp_bilinear_kernel<")
+    assert plan((1920, 1080), (1280, 720), B, aligned_outputs=False)["kernel"].startswith("vpp_bilinear_kernel<")
+
+
+def test_large_footprints_fall_back_to_smaller_workgroups_or_gathers():
+    p = plan((7680, 4320), (2560, 1440), C)            # 8K bicubic at ratio 3 (all weights zero -> point kernel)
+    assert p["kernel"].startswith("vpp_point_kernel")
+    p = plan((7680, 4320), (2800, 1576), C)            # 2.74: staged bicubic must fit the 40 KiB LDS budget
+    assert p["lds"] <= 40 * 1024 and p["kernel"].startswith(("vpp_bicubic_sep_kernel", "vpp_fused_gather_kernel"))
+
+
+def test_status_codes_match_convert():
+    fp = ts.FrameParameters(width=1281, height=720, resize_type=B)
+    with pytest.raises(RuntimeError, match="-2"):
+        ts.describe(fp, 1920, 1080)
+    fp = ts.FrameParameters(crop_coords=(100, 0, 2000, 720))  # smaller than the frame in both dimensions, but sticking out of it
+    with pytest.raises(RuntimeError, match="-3"):
+        ts.describe(fp, 1920, 1080)
