@@ -2337,10 +2337,10 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             return info ? hipSuccess : hipGetLastError();
         }
     }
-    if (vec)
-        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
-    else
-        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, false>", (vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0);
+    // every request takes the vector-store back end (unaligned outputs / two-column row tails fall back per thread
+    // inside color_store_tile); the gather kernel samples only the columns that exist
+    if (!vec) return hipErrorInvalidValue;
+    TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
     return info ? hipSuccess : hipGetLastError();
 }
 
