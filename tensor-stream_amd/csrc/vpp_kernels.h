@@ -73,6 +73,7 @@ struct LaunchDesc {
     int num_cus;            // compute units of the device (persistent grid sizing)
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
+    int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
     int scalar_stores;      // an output pointer is not 16-byte aligned: element-wise stores, same sampling kernels
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic

@@ -2381,7 +2381,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         shapes[0][0] = d.shape_tx;
         shapes[0][1] = d.shape_ty;
     }
-    constexpr size_t kLdsBudget = 40 * 1024;
+    const size_t kLdsBudget = (size_t)(d.lds_budget_kb > 0 ? d.lds_budget_kb : 40) * 1024; // TSVPP_LDS_KB
     bool staged = false;
     size_t lds_bytes = 0;
     auto workgroups = [&](const int *sh, int rpt) {
@@ -2446,60 +2446,89 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             // tiles 7 % faster -- and 14720 -- the headline, four-row tiles 3-7 % faster)
             const long rounds = (mode == M_BILINEAR || mode == M_AREA_UP) ? 48L : 16L;
             while (rpt_max > 1 && workgroups(sh, rpt_max) < rounds * d.num_cus) rpt_max--;
-            // separable BICUBIC: a taller tile that does not fit falls back to a shorter tile of the SAME workgroup
-            // shape before a smaller workgroup is tried (measured: 1080p -> 640x640, 375 k vs 288 k frames/s)
-            for (int rpt = rpt_max; rpt >= 1 && !staged; rpt = (sep || dyadic) ? rpt - 1 : 0) {
-                const int span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
+            // One (rows per thread, staging layout) candidate of this shape: its LDS need and descriptor fields.
+            struct Cand { bool ok; size_t need; int rpt, dma, span_y, rows_y, cpr_y, span_uv, rows_uv, cpr_uv; };
+            auto candidate = [&](int rpt, int layout) {
+                Cand c = {};
+                c.rpt = rpt;
+                c.span_y = span_bound(mode, sh[0] * PXW, d.xr, d.rx);
                 const int rows_y = span_bound(mode, sh[1] * PXH * rpt, d.yr, d.ry);
-                const int span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
+                c.span_uv = 2 * span_bound(mode, sh[0] * PXW / 2, d.xr, d.rx);
                 const int rows_uv = span_bound(mode, sh[1] * PXH * rpt / 2, d.yr, d.ry);
                 const int nthreads = sh[0] * sh[1];
-                // per shape: the LDS-DMA layout first (power-of-two chunks per row, rows padded to whole
-                // rounds), then the compact register-staged layout
-                for (int layout = want_dma ? 1 : 0; layout >= 0 && !staged; layout--) {
-                    int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
-                    if (cpr_y > nthreads || cpr_uv > nthreads) break;
-                    int rows_alloc_y = rows_y, rows_alloc_uv = rows_uv;
-                    const bool dma = layout == 1 && nthreads >= 64;
-                    if (layout == 1 && !dma) continue;
-                    if (dma) {
-                        cpr_y = 1 << slot_shift_for(cpr_y);
-                        cpr_uv = 1 << slot_shift_for(cpr_uv);
-                        const int rs_y = nthreads / cpr_y, rs_uv = nthreads / cpr_uv;
-                        rows_alloc_y = (rows_y + rs_y - 1) / rs_y * rs_y;
-                        rows_alloc_uv = (rows_uv + rs_uv - 1) / rs_uv * rs_uv;
-                    }
-                    size_t need = (size_t)16 * ((size_t)rows_alloc_y * cpr_y + (size_t)rows_alloc_uv * cpr_uv);
-                    if (mode == M_AREA_DOWN && d.qx && d.qy) // dyadic AREA: tables + row bases + slack for the dword over-read
-                        need += (size_t)sh[0] * PXW * sizeof(AXEntry) + (size_t)(sh[0] * PXW / 2) * sizeof(ACEntry) +
-                                (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(AYEntry) + sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv) + 32;
-                    if (area2) // column / row tables and row bases of the float AREA kernel
-                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(AFXEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(AFYEntry) +
-                                sizeof(int) * (size_t)(rows_alloc_y + rows_alloc_uv);
-                    if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
-                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * sizeof(XEntry) + (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * sizeof(YEntry);
-                    if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights (+ the H planes of the separable kernel)
-                        need += (size_t)(sh[0] * PXW + sh[0] * PXW / 2) * (sizeof(BXEntry) + sizeof(float)) +
-                                (size_t)(sh[1] * PXH * rpt + sh[1] * PXH * rpt / 2) * (sizeof(BYEntry) + sizeof(float)) +
-                                (sep ? (size_t)(rows_alloc_y + rows_alloc_uv) * sh[0] * PXW : 0);
-                    if (need > kLdsBudget) continue;
-                    staged = true;
-                    lds_bytes = need;
-                    d.tx = sh[0];
-                    d.ty = sh[1];
-                    d.rpt = rpt;
-                    d.lds_span_y = span_y;
-                    d.lds_rows_y = rows_alloc_y;
-                    d.lds_cpr_y = cpr_y;
-                    d.lds_slot_y = slot_shift_for(cpr_y);
-                    d.lds_span_uv = span_uv;
-                    d.lds_rows_uv = rows_alloc_uv;
-                    d.lds_cpr_uv = cpr_uv;
-                    d.lds_slot_uv = slot_shift_for(cpr_uv);
-                    d.dma = dma ? 1 : 0;
-                    if (mode == M_BICUBIC) d.bicubic_sep = sep ? 1 : 0;
-                    d.area2 = area2 ? 1 : 0;
+                c.cpr_y = (c.span_y + 15 + 15) / 16;
+                c.cpr_uv = (c.span_uv + 15 + 15) / 16;
+                if (c.cpr_y > nthreads || c.cpr_uv > nthreads) return c;
+                c.rows_y = rows_y;
+                c.rows_uv = rows_uv;
+                c.dma = (layout == 1 && nthreads >= 64) ? 1 : 0;
+                if (layout == 1 && !c.dma) return c;
+                if (c.dma) { // power-of-two chunks per row, rows padded to whole rounds
+                    c.cpr_y = 1 << slot_shift_for(c.cpr_y);
+                    c.cpr_uv = 1 << slot_shift_for(c.cpr_uv);
+                    const int rs_y = nthreads / c.cpr_y, rs_uv = nthreads / c.cpr_uv;
+                    c.rows_y = (rows_y + rs_y - 1) / rs_y * rs_y;
+                    c.rows_uv = (rows_uv + rs_uv - 1) / rs_uv * rs_uv;
                 }
+                const size_t cols = (size_t)sh[0] * PXW, rows = (size_t)sh[1] * PXH * rpt;
+                size_t need = (size_t)16 * ((size_t)c.rows_y * c.cpr_y + (size_t)c.rows_uv * c.cpr_uv);
+                if (dyadic) // tables + row bases + slack for the dword over-read
+                    need += cols * sizeof(AXEntry) + cols / 2 * sizeof(ACEntry) + (rows + rows / 2) * sizeof(AYEntry) +
+                            sizeof(int) * (size_t)(c.rows_y + c.rows_uv) + 32;
+                if (area2) // column / row tables and row bases of the float AREA kernel
+                    need += (cols + cols / 2) * sizeof(AFXEntry) + (rows + rows / 2) * sizeof(AFYEntry) + sizeof(int) * (size_t)(c.rows_y + c.rows_uv);
+                if (mode == M_BILINEAR || mode == M_AREA_UP) // coordinate tables
+                    need += (cols + cols / 2) * sizeof(XEntry) + (rows + rows / 2) * sizeof(YEntry);
+                if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights (+ the H planes of the separable kernel)
+                    need += (cols + cols / 2) * (sizeof(BXEntry) + sizeof(float)) + (rows + rows / 2) * (sizeof(BYEntry) + sizeof(float)) +
+                            (sep ? (size_t)(c.rows_y + c.rows_uv) * cols : 0);
+                c.need = need;
+                c.ok = need <= kLdsBudget;
+                return c;
+            };
+            Cand best = {};
+            if (dyadic) {
+                // the integer AREA kernel is sensitive to how many workgroups a CU holds (160 KiB of LDS): 1080p -> 960x540
+                // runs 560 k frames/s on the compact two-row layout (19.7 KiB, 8 workgroups), 523 k on the compact
+                // four-row one (34 KiB) and 494 k on the two-row LDS-DMA one (37.5 KiB).  Most resident workgroups
+                // (up to five) wins; ties go to the taller tile, then to LDS-DMA.
+                long best_key = -1;
+                for (int rpt = rpt_max; rpt >= 1; rpt--)
+                    for (int layout = want_dma ? 1 : 0; layout >= 0; layout--) {
+                        const Cand c = candidate(rpt, layout);
+                        if (!c.ok) continue;
+                        long occ = (long)(160 * 1024 / c.need);
+                        if (occ > 5) occ = 5; // beyond five resident workgroups the layout matters more (1080p -> 1536x864:
+                                              // four-row LDS-DMA tiles at 6 per CU, 283 k, vs compact ones at 8, 268 k)
+                        const long key = occ * 100 + rpt * 10 + c.dma;
+                        if (key > best_key) {
+                            best_key = key;
+                            best = c;
+                        }
+                    }
+            } else {
+                // first fit: the LDS-DMA layout, then the compact register-staged one; the separable BICUBIC kernel tries
+                // a shorter tile of the SAME workgroup shape before a smaller workgroup (1080p -> 640x640: 375 k vs 288 k)
+                for (int rpt = rpt_max; rpt >= 1 && !best.ok; rpt = sep ? rpt - 1 : 0)
+                    for (int layout = want_dma ? 1 : 0; layout >= 0 && !best.ok; layout--) best = candidate(rpt, layout);
+            }
+            if (best.ok) {
+                staged = true;
+                lds_bytes = best.need;
+                d.tx = sh[0];
+                d.ty = sh[1];
+                d.rpt = best.rpt;
+                d.lds_span_y = best.span_y;
+                d.lds_rows_y = best.rows_y;
+                d.lds_cpr_y = best.cpr_y;
+                d.lds_slot_y = slot_shift_for(best.cpr_y);
+                d.lds_span_uv = best.span_uv;
+                d.lds_rows_uv = best.rows_uv;
+                d.lds_cpr_uv = best.cpr_uv;
+                d.lds_slot_uv = slot_shift_for(best.cpr_uv);
+                d.dma = best.dma;
+                if (mode == M_BICUBIC) d.bicubic_sep = sep ? 1 : 0;
+                d.area2 = area2 ? 1 : 0;
             }
         }
     }

@@ -59,7 +59,11 @@ def test_small_outputs_keep_two_row_thread_tiles():
     assert plan((1920, 1080), (1280, 720), B, n_frames=64)["rpt"] == 2   # 14720 >= 12288
     assert plan((1920, 1080), (960, 540), B, n_frames=64)["rpt"] == 1    # 8704: measured 7 % faster with two-row tiles
     assert plan((3840, 2160), (1920, 1080), B, n_frames=64)["rpt"] == 2
-    assert plan((1920, 1080), (960, 540), A, n_frames=64)["rpt"] == 2    # dyadic AREA: four-row tiles from 4096 workgroups
+    # dyadic AREA: most resident workgroups first (1080p -> 960x540: the compact two-row layout, 19.7 KiB, 8 per CU)
+    p = plan((1920, 1080), (960, 540), A, n_frames=64)
+    assert (p["rpt"], p["dma"]) == (1, 0) and p["lds"] < 20 * 1024
+    p = plan((1920, 1080), (1536, 864), A, n_frames=64)                  # >= 5 per CU either way: taller tile, LDS-DMA
+    assert (p["rpt"], p["dma"]) == (2, 1)
 
 
 def test_output_flavours_share_the_sampling_kernels():
