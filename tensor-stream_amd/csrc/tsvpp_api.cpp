@@ -473,10 +473,9 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
-    // Every request runs on the vector-store kernels.  dst_w is even; when it is 4 k + 2 the last thread tile of a row
-    // stores its two columns element-wise (rows then start 8 bytes / 2 bytes off the vector alignment, which global
-    // stores tolerate); when an output pointer is not 16-byte aligned every thread does.
-    const bool vec = true;
+    // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel).  dst_w is even; when it
+    // is 4 k + 2 the last thread tile of a row converts its two columns on the generic element-wise path (rows then
+    // start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
     bool aligned_out = true;
     for (int f = 0; f < n; f++) {
         if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
@@ -490,7 +489,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
 
     LaunchDesc d;
     fill_desc(ctx, pl, pitch_y, pitch_uv, d);
-    d.scalar_stores = aligned_out ? 0 : 1;
+    bool vec = aligned_out;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;
         sts = get_area_table(ctx, pl.xr, tx);
@@ -546,7 +545,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     }
     const OutKind out_kind = pl.out;
     if (two_pass) {
-        d.scalar_stores = 0; // scratch frames are 256-byte aligned
+        vec = true; // scratch frames are 256-byte aligned
         if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     }
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
@@ -625,7 +624,6 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
     read_env_knobs(&tmp);
     LaunchDesc d;
     fill_desc(&tmp, pl, pitch_y, pitch_uv, d);
-    d.scalar_stores = aligned_outputs ? 0 : 1;
     // frame pointers are assumed 256-byte aligned; the crop origin decides the rest
     d.in_aligned4 = (pitch_y % 4 == 0 && pitch_uv % 4 == 0 && ((size_t)pl.off_y * pitch_y + pl.off_x) % 4 == 0 &&
                      ((size_t)(pl.off_y / 2) * pitch_uv + pl.off_x) % 4 == 0)
@@ -658,7 +656,6 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
         }
     }
     const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
-    if (two_pass) d.scalar_stores = 0;
     d.n_frames = n_frames < TSVPP_MAX_BATCH ? n_frames : TSVPP_MAX_BATCH;
     static const char *const out_names[O_COUNT] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32" };
     static const char *const mode_names[M_COUNT] = { "none", "nearest", "bilinear", "bicubic", "area_down", "area_up" };
@@ -666,7 +663,7 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
     info.kernel = "(none)";
     if (!(two_pass && pl.mode == M_NONE)) {
         FrameTable t = {};
-        hipError_t e = launch_fused(pl.mode, pl.out, true, d, t, nullptr, &info);
+        hipError_t e = launch_fused(pl.mode, pl.out, aligned_outputs != 0 || two_pass, d, t, nullptr, &info);
         if (e != hipSuccess) return (int)e;
     }
     char kname[128]; // the launcher's spelling without blanks: one token per key=value pair
@@ -674,9 +671,9 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
     for (const char *c = info.kernel; *c && kn + 1 < sizeof(kname); c++)
         if (*c != ' ') kname[kn++] = *c;
     kname[kn] = 0;
-    std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d%s",
+    std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d tail=%d%s",
                   mode_names[pl.mode], out_names[pl.out], pl.src_w, pl.src_h, pl.dst_w, pl.dst_h, kname, info.tx, info.ty, info.rpt, info.dma,
-                  info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames,
+                  info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames, info.tail,
                   two_pass ? (pl.fourcc == TSVPP_UYVY ? " pass2=fmt_uyvy" : " pass2=fmt_yuv444") : "");
     return TSVPP_OK;
 }

@@ -73,8 +73,8 @@ struct LaunchDesc {
     int num_cus;            // compute units of the device (persistent grid sizing)
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
+    int col0;               // first output column of this launch (0; dst_w & ~3 in the row-tail launch of widths 4 k + 2)
     int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
-    int scalar_stores;      // an output pointer is not 16-byte aligned: element-wise stores, same sampling kernels
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
 };
@@ -90,10 +90,11 @@ enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O
 struct LaunchInfo {
     const char *kernel;
     int tx, ty, rpt, dma, staged, lds_bytes, grid, tiles_x, tiles_y;
+    int tail; // a second, element-wise launch covers the two-column row tail (dst_w = 4 k + 2)
 };
 
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector
-// store path (needs 16-byte aligned outputs; a row's last thread tile stores scalar when dst_w = 4 k + 2).
+// store path (needs 16-byte aligned outputs; when dst_w = 4 k + 2 a row's last thread tile takes the generic path).
 // Returns hipError_t.
 // `info` != nullptr: a dry run -- the selection is recorded there and nothing is launched.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info = nullptr);

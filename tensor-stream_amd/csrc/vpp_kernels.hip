@@ -565,12 +565,6 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
                                                  typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
-    if constexpr (VEC) { // dst_w = 4 k + 2: the row's last thread tile has two columns; it alone takes the scalar path
-        if (d.dst_w - j0 < PXW || d.scalar_stores) { // (or every thread, when an output is not 16-byte aligned)
-            color_store_tile<OUT, false>(Yf, Uf, Vf, d, out, i0, j0, min(PXW, d.dst_w - j0));
-            return;
-        }
-    }
     if constexpr (OUT == O_NV12_U8 || OUT == O_NV12_F32 || OUT == O_Y800_U8 || OUT == O_Y800_F32) {
         // no colour conversion: the resized samples themselves (fp32: / 255), Y plane then UV plane
         using T = typename OutT<OUT>::type;
@@ -676,27 +670,33 @@ __device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
 // Generic thread tile: samplers (any mode, any reader) -> colour back end.
 template <int MODE, int OUT, bool VEC, class S>
 __device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc &d, typename OutT<OUT>::type *out, int i0, int j0) {
-    const int ncol = min(PXW, d.dst_w - j0); // dst_w is even: 2 or 4 (2 only in the last thread tile of a row)
-    const int ci = i0 >> 1, cj0 = j0 >> 1;
+    // VEC: the thread tile has its four columns.  Element-wise flavour: dst_w is even, so 2 or 4 columns (2 in the last
+    // thread tile of a row when dst_w = 4 k + 2); a column that does not exist is sampled at the row's last one
+    // instead -- in bounds, branch-free -- and never stored.
+    const int ncol = VEC ? PXW : min(PXW, d.dst_w - j0);
+    const int ci = i0 >> 1, cj0 = j0 >> 1, jmax = d.dst_w - 1, cjmax = (d.dst_w >> 1) - 1;
     float Uf[2], Vf[2], Yf[PXH][PXW];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         int U = 128, V = 128;
-        if constexpr (!kLumaOnly<OUT>)
-            if (2 * c < ncol) sample_chroma<MODE>(s, d, ci, cj0 + c, U, V);
+        if constexpr (!kLumaOnly<OUT>) sample_chroma<MODE>(s, d, ci, VEC ? cj0 + c : min(cj0 + c, cjmax), U, V);
         Uf[c] = (float)U;
         Vf[c] = (float)V;
     }
 #pragma unroll
     for (int r = 0; r < PXH; r++)
 #pragma unroll
-        for (int c = 0; c < PXW; c++) {
-            int Y = 0;
-            if (c < ncol) Y = sample_luma<MODE>(s, d, i0 + r, j0 + c);
-            Yf[r][c] = (float)Y;
-        }
+        for (int c = 0; c < PXW; c++) Yf[r][c] = (float)sample_luma<MODE>(s, d, i0 + r, VEC ? j0 + c : min(j0 + c, jmax));
     color_store_tile<OUT, VEC>(Yf, Uf, Vf, d, out, i0, j0, ncol);
 }
+
+// dst_w = 4 k + 2 (854, 1366, ...): the last thread tile of every row has only two columns.  The vector-store kernels
+// skip it (is_row_tail) and launch_fused covers those two columns with a second, tiny launch of the element-wise
+// gather kernel (one thread tile per row pair; LaunchDesc::col0).  Both cheaper alternatives were measured and
+// rejected: a fallback at store time keeps every sample live across its branch (gather / direct / colour-only
+// kernels 4-10 % slower although it is almost never taken), and an early exit into an inlined generic path drags that
+// path's registers into every kernel (C4's point kernel: 30 -> 110 VGPRs, 25 % slower).
+__device__ __forceinline__ bool is_row_tail(const LaunchDesc &d, int j0) { return d.dst_w - j0 < PXW; }
 
 // ----------------------------------------------------------------------------------------------
 // Fallback kernel: taps gathered byte-wise from global memory (any size, any alignment).
@@ -706,9 +706,10 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_gather_kernel(const Lau
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = (id.tx * d.tx + lx) * PXW;
+    const int j0 = (id.tx * d.tx + lx) * PXW + d.col0;
     const int i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (VEC && is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     GlobalSrc s;
     s.y = t.y[id.frame];
     s.uv = t.uv[id.frame];
@@ -901,6 +902,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const Lau
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     convert_thread_tile<MODE, OUT, true>(s, d, (T *)t.out[id.frame], i0, j0);
 }
 
@@ -1093,6 +1095,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW;
     if (j0 >= d.dst_w) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     // thread tile = 4 columns x (2 * rpt) rows: the tile decode, the staging set-up and the table build are
     // paid once per 8 * rpt pixels
     for (int rp = 0; rp < d.rpt; rp++) {
@@ -1206,6 +1209,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_areaf_kernel(const LaunchDesc
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW;
     if (j0 >= d.dst_w) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     AFXEntry xe[PXW], cxe[2];
 #pragma unroll
     for (int c = 0; c < PXW; c++) xe[c] = xtab[lx * PXW + c];
@@ -1346,6 +1350,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_kernel(const LaunchDe
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
 
     float Uf[2], Vf[2], Yf[PXH][PXW];
     { // chroma: (U, V) evaluated as a pair -- same weights, tap addresses one byte apart
@@ -1560,6 +1565,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_sep_kernel(const Laun
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW;
     if (j0 >= d.dst_w) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     for (int rp = 0; rp < d.rpt; rp++) {
         const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
         if (i0 >= d.dst_h) break;
@@ -1792,6 +1798,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = f.j_first + lx * PXW;
     if (j0 >= d.dst_w) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     // thread tile = 4 columns x (2 * rpt) rows: tile decode, staging set-up and table build are paid once per 8 * rpt pixels
     for (int rp = 0; rp < d.rpt; rp++) {
     const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
@@ -1908,6 +1915,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
     const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
     const int ci = i0 >> 1, cj0 = j0 >> 1;
@@ -1920,9 +1928,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
         int xo[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int cj = min(cj0 + c, (d.dst_w >> 1) - 1); // a row's last thread tile may have two columns: never address past them
-            qx[c] = d.qx[cj % d.nx];
-            xo[c] = 2 * (int)(d.xr * (float)cj);
+            qx[c] = d.qx[(cj0 + c) % d.nx];
+            xo[c] = 2 * (int)(d.xr * (float)(cj0 + c));
         }
         uint32_t su[2] = { 0, 0 }, sv[2] = { 0, 0 };
         for (int a = 0; a < d.ry; a++) {
@@ -1956,9 +1963,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
         uint32_t w0[PXW], w1[PXW];
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
-            const int j = min(j0 + c, d.dst_w - 1);
-            const AreaQRow q = d.qx[j % d.nx];
-            xo[c] = (int)(d.xr * (float)j);
+            const AreaQRow q = d.qx[(j0 + c) % d.nx];
+            xo[c] = (int)(d.xr * (float)(j0 + c));
             xs[c] = q.sum;
             w0[c] = q.w[0];
             w1[c] = q.w[1];
@@ -2006,6 +2012,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
     const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
     const int ci = i0 >> 1, cj0 = j0 >> 1;
@@ -2016,9 +2023,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
         const int y0 = (int)(d.yr * (float)ci);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int cj = min(cj0 + c, (d.dst_w >> 1) - 1); // a row's last thread tile may have two columns: never address past them
-            const int x0 = 2 * (int)(d.xr * (float)cj);
-            const float *wxrow = d.patx4 + (cj % d.nx) * 4 * NK;
+            const int x0 = 2 * (int)(d.xr * (float)(cj0 + c));
+            const float *wxrow = d.patx4 + ((cj0 + c) % d.nx) * 4 * NK;
             vf4 wx[NK];
 #pragma unroll
             for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
@@ -2061,9 +2067,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
         vf4 wx[PXW][NK];
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
-            const int j = min(j0 + c, d.dst_w - 1);
-            x0[c] = (int)(d.xr * (float)j);
-            const float *wxrow = d.patx4 + (j % d.nx) * 4 * NK;
+            x0[c] = (int)(d.xr * (float)(j0 + c));
+            const float *wxrow = d.patx4 + ((j0 + c) % d.nx) * 4 * NK;
 #pragma unroll
             for (int k = 0; k < NK; k++) wx[c][k] = *(const vf4a4 *)(wxrow + 4 * k);
         }
@@ -2178,6 +2183,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_point_kernel(const LaunchDesc
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
     const int j0 = j_first + lx * PXW, i0 = i_first + ly * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const int4 xo = *(const int4 *)(xtab + lx * PXW);
     const int2 cxo = *(const int2 *)(cxtab + lx * 2);
     const int2 yo = *(const int2 *)(ytab + ly * PXH);
@@ -2210,6 +2216,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_color_kernel(const LaunchDesc
     const int j0 = (id.tx * d.tx + lx) * PXW;
     const int i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const uint8_t *py = t.y[id.frame] + (size_t)i0 * (size_t)d.pitch_y + (size_t)j0;
     const uint32_t yw[2] = { *(const uint32_t *)py, *(const uint32_t *)(py + d.pitch_y) };
     const uint32_t c = *(const uint32_t *)(t.uv[id.frame] + (size_t)(i0 >> 1) * (size_t)d.pitch_uv + (size_t)j0);
@@ -2278,7 +2285,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
             // persistent variant: two LDS tile sets filled by LDS-DMA
-            if (d.persist > 0 && d.dma && 2 * lds_bytes <= 64 * 1024) {
+            if (d.persist > 0 && d.dma && 2 * lds_bytes <= 64 * 1024 && (d.dst_w & 3) == 0) { // (no row-tail path in that kernel)
                 const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
                 const long resident = (long)d.num_cus * d.persist;
                 dim3 pgrid((unsigned)(total < resident ? total : resident));
@@ -2337,10 +2344,10 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             return info ? hipSuccess : hipGetLastError();
         }
     }
-    // every request takes the vector-store back end (unaligned outputs / two-column row tails fall back per thread
-    // inside color_store_tile); the gather kernel samples only the columns that exist
-    if (!vec) return hipErrorInvalidValue;
-    TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
+    if (vec)
+        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
+    else // outputs that are not 16-byte aligned: element-wise stores
+        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, false>", (vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0);
     return info ? hipSuccess : hipGetLastError();
 }
 
@@ -2553,15 +2560,39 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         info->tiles_x = d.tiles_x;
         info->tiles_y = d.tiles_y;
     }
-    switch (mode) {
-    case M_NONE: return launch_m<M_NONE>(out, vec, staged, d, t, lds_bytes, stream, info);
-    case M_NEAREST: return launch_m<M_NEAREST>(out, vec, staged, d, t, lds_bytes, stream, info);
-    case M_BILINEAR: return launch_m<M_BILINEAR>(out, vec, staged, d, t, lds_bytes, stream, info);
-    case M_BICUBIC: return launch_m<M_BICUBIC>(out, vec, staged, d, t, lds_bytes, stream, info);
-    case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, vec, staged, d, t, lds_bytes, stream, info);
-    case M_AREA_UP: return launch_m<M_AREA_UP>(out, vec, staged, d, t, lds_bytes, stream, info);
-    default: return hipErrorInvalidValue;
+    auto dispatch = [&](bool v, bool st, LaunchDesc &dd, size_t lds, LaunchInfo *inf) {
+        switch (mode) {
+        case M_NONE: return launch_m<M_NONE>(out, v, st, dd, t, lds, stream, inf);
+        case M_NEAREST: return launch_m<M_NEAREST>(out, v, st, dd, t, lds, stream, inf);
+        case M_BILINEAR: return launch_m<M_BILINEAR>(out, v, st, dd, t, lds, stream, inf);
+        case M_BICUBIC: return launch_m<M_BICUBIC>(out, v, st, dd, t, lds, stream, inf);
+        case M_AREA_DOWN: return launch_m<M_AREA_DOWN>(out, v, st, dd, t, lds, stream, inf);
+        case M_AREA_UP: return launch_m<M_AREA_UP>(out, v, st, dd, t, lds, stream, inf);
+        default: return hipErrorInvalidValue;
+        }
+    };
+    hipError_t e = dispatch(vec, staged, d, lds_bytes, info);
+    if (e != hipSuccess || !vec || (d.dst_w & 3) == 0) return e;
+    // dst_w = 4 k + 2: the vector-store kernels left the last two columns of every row alone (is_row_tail); one more,
+    // tiny launch of the element-wise gather kernel converts them: workgroup = 1 x 256 thread tiles of 2 columns x 2 rows
+    if (info) {
+        info->tail = 1;
+        return e;
     }
+    LaunchDesc td = d;
+    td.col0 = d.dst_w & ~3;
+    td.tx = 1;
+    td.ty = MAX_THREADS;
+    td.tx_shift = 0;
+    td.rpt = 1;
+    td.dma = 0;
+    td.point_kind = PK_NONE; // the generic samplers give the point samplers' values (all weights are zero)
+    td.area_direct = 0;
+    td.tiles_x = 1;
+    td.tiles_y = (d.dst_h + MAX_THREADS * PXH - 1) / (MAX_THREADS * PXH);
+    const long rows = (long)td.tiles_y * td.n_frames;
+    td.blocks_per_xcd = (int)((rows + NUM_XCD - 1) / NUM_XCD); // tiles_x == 1: the same for every tile order
+    return dispatch(false, false, td, 0, nullptr);
 }
 
 } // namespace tsvpp

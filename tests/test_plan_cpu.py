@@ -77,11 +77,13 @@ def test_output_flavours_share_the_sampling_kernels():
     assert p["kernel"] == "(none)" and p["pass2"] == "fmt_yuv444"        # no resize: the format kernel reads the input itself
 
 
-def test_widths_4k_plus_2_and_unaligned_outputs_stay_on_the_fast_kernels():
+def test_widths_4k_plus_2_stay_on_the_fast_kernels_and_unaligned_outputs_gather():
     assert plan((1920, 1080), (854, 480), A)["kernel"].startswith("vpp_area_direct_float_kernel<1")
     assert plan((1920, 1080), (1366, 768), A)["kernel"].startswith("vpp_areaf_kernel<2,2")
-    assert plan((1920, 1080), (854, 480), B)["kernel"].startswith("vpp_bilinear_kernel<")
-    assert plan((1920, 1080), (1280, 720), B, aligned_outputs=False)["kernel"].startswith("vpp_bilinear_kernel<")
+    p = plan((1920, 1080), (854, 480), B)
+    assert p["kernel"].startswith("vpp_bilinear_kernel<") and p["tail"] == 1   # + the two-column row-tail launch
+    assert plan((1920, 1080), (1280, 720), B)["tail"] == 0
+    assert plan((1920, 1080), (1280, 720), B, aligned_outputs=False)["kernel"] == "vpp_fused_gather_kernel<MODE,OUT,false>"
 
 
 def test_large_footprints_fall_back_to_smaller_workgroups_or_gathers():
