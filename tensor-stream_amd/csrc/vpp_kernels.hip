@@ -2574,7 +2574,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     hipError_t e = dispatch(vec, staged, d, lds_bytes, info);
     if (e != hipSuccess || !vec || (d.dst_w & 3) == 0) return e;
     // dst_w = 4 k + 2: the vector-store kernels left the last two columns of every row alone (is_row_tail); one more,
-    // tiny launch of the element-wise gather kernel converts them: workgroup = 1 x 256 thread tiles of 2 columns x 2 rows
+    // tiny launch of the element-wise gather kernel converts them: workgroup = 1 x 64 thread tiles of 2 columns x 2 rows
     if (info) {
         info->tail = 1;
         return e;
@@ -2582,14 +2582,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     LaunchDesc td = d;
     td.col0 = d.dst_w & ~3;
     td.tx = 1;
-    td.ty = MAX_THREADS;
+    td.ty = 64; // one wave per workgroup: the few thousand tail threads spread over all CUs
     td.tx_shift = 0;
     td.rpt = 1;
     td.dma = 0;
     td.point_kind = PK_NONE; // the generic samplers give the point samplers' values (all weights are zero)
     td.area_direct = 0;
     td.tiles_x = 1;
-    td.tiles_y = (d.dst_h + MAX_THREADS * PXH - 1) / (MAX_THREADS * PXH);
+    td.tiles_y = (d.dst_h + td.ty * PXH - 1) / (td.ty * PXH);
     const long rows = (long)td.tiles_y * td.n_frames;
     td.blocks_per_xcd = (int)((rows + NUM_XCD - 1) / NUM_XCD); // tiles_x == 1: the same for every tile order
     return dispatch(false, false, td, 0, nullptr);
