@@ -216,7 +216,7 @@ def main():
         frames_per_launch = B / launches_per_step
         achieved = bytes_per_frame * frames_per_launch / (kernel_ms * 1e-3) / 1e9
         res = {
-            "metric": "1080p NV12->720p BGR24 planar fp32 frames/sec per GPU; achieved HBM GB/s vs roofline"
+            "metric": "1080p NV12\u2192720p BGR24 planar fp32 frames/sec per GPU; achieved HBM GB/s vs roofline"
             if args.workload == "headline" else f"{args.workload} frames/sec",
             "value": round(frames / wall, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
