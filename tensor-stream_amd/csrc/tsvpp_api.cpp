@@ -158,6 +158,7 @@ struct tsvpp_ctx {
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
+    int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 2;                    // TSVPP_RPT
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
@@ -248,6 +249,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
 }
@@ -280,6 +282,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.bicubic_sep = ctx->bicubic_sep;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
+    d.area_cols_pref = ctx->area_cols;
     d.num_cus = ctx->num_cus;
 }
 

@@ -73,6 +73,7 @@ struct LaunchDesc {
     int num_cus;            // compute units of the device (persistent grid sizing)
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
+    int area_cols_pref, area_cols; // column-per-lane float AREA kernel allowed (TSVPP_AREA_COLS) / chosen by launch_fused
     int col0;               // first output column of this launch (0; dst_w & ~3 in the row-tail launch of widths 4 k + 2)
     int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled

@@ -2122,6 +2122,150 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
 }
 
 // ----------------------------------------------------------------------------------------------
+// Large-ratio AREA with float weights, one output COLUMN per lane.  The kernel above gives every lane a 4-column
+// thread tile: neighbouring lanes then read windows 4 * xr (34 bytes at 1080p -> 224) apart and each load instruction
+// of a wave touches ~34 cache lines for 128-512 useful bytes -- the texture-address path, not HBM or the VALU, bounds
+// it (1080p -> 224x224: 30 % of the ROI roofline).  Here the sampling runs with lane = column (stride xr bytes: a wave's
+// load covers ONE contiguous 64 * xr byte run, ~9 lines), two output rows per lane at a time on float pairs, and the
+// resized samples go through a 12 KiB LDS tile into the usual 2 x 4 thread tiles for colour conversion and stores.
+// Workgroup = 16 x 16 thread tiles = 64 columns x 32 rows; wave w samples rows 8 w .. 8 w + 7 (chroma 4 w .. 4 w + 3).
+// Arithmetic and accumulation order are the reference's (src/Resize.cu:160-178), as in the kernel above.
+template <int NK> struct ColWeights { vf4 w[NK]; };
+
+template <int NK>
+__device__ __forceinline__ void cols_load(const uint8_t *plane, uint32_t pm, uint32_t off, int nbytes, bool wide, uint32_t (&dw)[NK + 1], uint32_t &sh) {
+    if constexpr (NK <= 2) {
+        if (wide) load_span<NK, true>(plane, pm, off, nbytes, dw, sh);
+        else load_span<NK, false>(plane, pm, off, nbytes, dw, sh);
+    } else {
+        const uint32_t o = off + pm;
+        sh = o & 3u;
+        const uint32_t *p = (const uint32_t *)(plane + (o - sh));
+#pragma unroll
+        for (int k = 0; k <= NK; k++) dw[k] = p[(wide || 4 * k < (int)sh + nbytes) ? k : 0];
+    }
+}
+
+template <int NK, int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    constexpr int TW = 64, TH = 32; // output tile of the workgroup (tx = ty = 16 thread tiles)
+    __shared__ __attribute__((aligned(16))) float yt[TH][TW];
+    __shared__ __attribute__((aligned(16))) f2 uvt[TH / 2][TW / 2];
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int j_first = id.tx * TW, i_first = id.ty * TH;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
+    const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
+
+    { // luma: lane = column; columns / rows past the frame are computed on the last valid one and never used
+        const int j = min(j_first + lane, d.dst_w - 1);
+        const int x0 = (int)(d.xr * (float)j);
+        const float *wxrow = d.patx4 + (j % d.nx) * 4 * NK;
+        vf4 wx[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
+        for (int rp = 0; rp < 4; rp++) {
+            const int r0 = 8 * wave + 2 * rp;
+            const int iA = min(i_first + r0, d.dst_h - 1), iB = min(i_first + r0 + 1, d.dst_h - 1);
+            const float *wyA = d.paty4 + (iA % d.ny) * 4 * d.nky, *wyB = d.paty4 + (iB % d.ny) * 4 * d.nky;
+            const int yA = (int)(d.yr * (float)iA), yB = (int)(d.yr * (float)iB);
+            f2 acc = { 0.0f, 0.0f }, div = { 0.0f, 0.0f };
+            for (int a = 0; a < d.ry; a++) {
+                const f2 wy = { wyA[a], wyB[a] };
+                uint32_t da[NK + 1], db[NK + 1], sa, sb;
+                cols_load<NK>(Y, ym, (uint32_t)(yA + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yA + a) < d.src_h - 1, da, sa);
+                cols_load<NK>(Y, ym, (uint32_t)(yB + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yB + a) < d.src_h - 1, db, sb);
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const uint32_t va = __builtin_amdgcn_alignbyte(da[k + 1], da[k], sa), vb = __builtin_amdgcn_alignbyte(db[k + 1], db[k], sb);
+                    const float wk[4] = { wx[k].x, wx[k].y, wx[k].z, wx[k].w };
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const f2 wgt = (f2){ wk[b], wk[b] } * wy;
+                        div = div + wgt;
+                        acc = acc + (f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) } * wgt;
+                    }
+                }
+            }
+            yt[r0][lane] = __builtin_truncf(acc.x / div.x);
+            yt[r0 + 1][lane] = __builtin_truncf(acc.y / div.y);
+        }
+    }
+    if (!d.luma_only) { // chroma: lanes 0-31 / 32-63 = the 32 chroma columns of two chroma rows; (U, V) as a pair
+        const int cw = d.dst_w >> 1, chh = d.dst_h >> 1;
+        const int cj = min((j_first >> 1) + (lane & 31), cw - 1);
+        const int x0 = 2 * (int)(d.xr * (float)cj);
+        const float *wxrow = d.patx4 + (cj % d.nx) * 4 * NK;
+        vf4 wx[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
+        for (int q = 0; q < 2; q++) {
+            const int cr = 4 * wave + 2 * q + (lane >> 5);
+            const int ci = min((i_first >> 1) + cr, chh - 1);
+            const float *wyrow = d.paty4 + (ci % d.ny) * 4 * d.nky;
+            const int y0 = (int)(d.yr * (float)ci);
+            f2 acc = { 0.0f, 0.0f };
+            float div = 0.0f;
+            for (int a = 0; a < d.ry; a++) {
+                const float wy = wyrow[a];
+                const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_uv + (uint32_t)x0;
+                const bool wide = (y0 + a) < (d.src_h >> 1) - 1;
+                uint32_t dw[2 * NK + 1], sh;
+                if constexpr (NK == 1) {
+                    if (wide) load_span<2, true>(UV, uvm, row, 2 * d.rx, dw, sh);
+                    else load_span<2, false>(UV, uvm, row, 2 * d.rx, dw, sh);
+                } else {
+                    sh = (uvm + row) & 3u;
+                    const uint32_t *p = (const uint32_t *)(UV + (row + uvm - sh));
+#pragma unroll
+                    for (int k = 0; k <= 2 * NK; k++) dw[k] = p[(wide || 4 * k < (int)sh + 2 * d.rx) ? k : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const uint32_t v0 = __builtin_amdgcn_alignbyte(dw[2 * k + 1], dw[2 * k], sh);     // U0 V0 U1 V1
+                    const uint32_t v1 = __builtin_amdgcn_alignbyte(dw[2 * k + 2], dw[2 * k + 1], sh); // U2 V2 U3 V3
+                    const float wv[4] = { wx[k].x, wx[k].y, wx[k].z, wx[k].w };
+                    const uint32_t vv[2] = { v0, v1 };
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t qq = vv[b >> 1] >> (16 * (b & 1));
+                        const float wgt = wv[b] * wy;
+                        div = div + wgt;
+                        acc = acc + (f2){ (float)(qq & 255), (float)((qq >> 8) & 255) } * (f2){ wgt, wgt };
+                    }
+                }
+            }
+            uvt[cr][lane & 31] = (f2){ __builtin_truncf(acc.x / div), __builtin_truncf(acc.y / div) };
+        }
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int j0 = j_first + lx * PXW, i0 = i_first + ly * PXH;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const vf4 v = *(const vf4 *)&yt[ly * PXH + r][lx * PXW];
+        Yf[r][0] = v.x;
+        Yf[r][1] = v.y;
+        Yf[r][2] = v.z;
+        Yf[r][3] = v.w;
+    }
+    {
+        const vf4 c = *(const vf4 *)&uvt[ly][lx * 2];
+        Uf[0] = c.x;
+        Vf[0] = c.y;
+        Uf[1] = c.z;
+        Vf[1] = c.w;
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Point-sampling kernel: NEAREST, and BILINEAR / BICUBIC requests whose weights are all zero.
 // Every output row needs exactly ONE source row and every output column one source byte (pair),
 // so only those rows are staged -- a 3x down-scale reads a third of the luma plane -- one LDS row
@@ -2308,6 +2452,12 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
+            if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // the same, one output column per lane
+                if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, OUT>", (vpp_area_cols_kernel<1, OUT>), grid, block, 0);
+                else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, OUT>", (vpp_area_cols_kernel<2, OUT>), grid, block, 0);
+                else TSVPP_LAUNCH("vpp_area_cols_kernel<3, OUT>", (vpp_area_cols_kernel<3, OUT>), grid, block, 0);
+                return info ? hipSuccess : hipGetLastError();
+            }
             if (vec && d.area_direct == 2 && !d.force_gather) { // large non-dyadic ratios: float sums straight from global memory
                 if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_direct_float_kernel<1, OUT>", (vpp_area_direct_float_kernel<1, OUT>), grid, block, 0);
                 else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_direct_float_kernel<2, OUT>", (vpp_area_direct_float_kernel<2, OUT>), grid, block, 0);
@@ -2404,6 +2554,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.area_direct = 2; // float weights
     else
         d.area_direct = 0;
+    // measured (tools/ab: TSVPP_AREA_COLS=0/1/2): the column-per-lane kernel wins at 5-8 horizontal taps (1080p -> 300^2
+    // +17 %, -> 416^2 +34 %, 4K -> 608x342 +11 %), is even at 2-4 and loses at 9+ (1080p -> 224^2 -6 %: 102 VGPRs and
+    // half-empty 64 x 32 tiles); 2 = always
+    d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx == 2))) ? 1 : 0;
+    if (d.area_cols) { // fixed workgroup: 16 x 16 thread tiles = 64 columns x 32 rows
+        d.tx = 16;
+        d.ty = 16;
+    }
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
     if (point && vec && !d.force_gather) {

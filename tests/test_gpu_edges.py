@@ -217,3 +217,24 @@ def test_widths_of_the_form_4k_plus_2_stay_on_the_fast_kernels(vpp, oracle, rt):
     conv(vpp, oracle, y, uv, width=1366, planes=0, norm=True)
     conv(vpp, oracle, y, uv, width=1366, crop=(4, 2, 1362, 766), planes=0, norm=False)
     conv(vpp, oracle, y, uv, width=1366, crop=(0, 0, 1362, 760), dst=(0, 0), fourcc=5, norm=True)
+
+
+@pytest.mark.parametrize("cols", ["0", "2"])
+def test_large_ratio_float_area_both_samplers(oracle, monkeypatch, cols):
+    """Non-dyadic AREA at ratios >= 2 has two samplers -- a 4-column thread tile per lane and one output column per lane
+    (the default picks by tap count); both must give the reference's bits for 2-4, 5-8 and 9-12 horizontal taps, every
+    output flavour, partial 64 x 32 tiles, 4 k + 2 widths and crops with misaligned origins."""
+    import tensor_stream as ts
+    monkeypatch.setenv("TSVPP_AREA_COLS", cols)
+    v = ts.VideoProcessor(device=0, max_consumers=2)
+    try:
+        y, uv = synth_nv12(1920, 1080, seed=515, pitch=1936)
+        for dst in [(800, 450), (300, 300), (416, 234), (224, 224), (174, 98), (854, 480)]:
+            conv(v, oracle, y, uv, width=1920, dst=dst, rt=3, planes=0, norm=True)
+            conv(v, oracle, y, uv, width=1920, dst=dst, rt=3, planes=1, norm=True)
+            conv(v, oracle, y, uv, width=1920, dst=dst, rt=3, planes=1, norm=False)
+            conv(v, oracle, y, uv, width=1920, dst=dst, rt=3, fourcc=0, norm=False)
+        conv(v, oracle, y, uv, width=1920, crop=(1, 1, 1501, 901), dst=(224, 224), rt=3, planes=0, norm=True)
+        conv(v, oracle, y, uv, width=1920, crop=(3, 2, 1603, 902), dst=(300, 170), rt=3, planes=0, norm=False)
+    finally:
+        v.Close()

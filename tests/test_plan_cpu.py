@@ -38,6 +38,7 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
     ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
     ((1920, 1080), (224, 224), A, "vpp_area_direct_float_kernel<3"),     # 8.57 x 4.82
+    ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2"),             # 6.4 x 3.6: one output column per lane
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<MODE==M_AREA_UP"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_sep_kernel"),
     ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
