@@ -240,6 +240,26 @@ def main():
                 res["roofline"]["traffic_source"] = f"profiles/traffic_latest.json ({tr['round']}): 2*FETCH_SIZE+WRITE_SIZE, KiB"
         except (OSError, ValueError, KeyError):
             pass
+        # BASELINE.json's metric names no resize type ("report all four"): the timed region above is
+        # BILINEAR; the other three on the same buffers, 20 launches each, outside the timed region
+        if world == 1 and args.workload == "headline" and not args.resize and not args.no_cpu_baseline:
+            others = {}
+            for name in ("NEAREST", "BICUBIC", "AREA"):
+                fp2 = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=RESIZE[name],
+                                         pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
+                vpp.prepare(fp2, src_w, src_h)
+                bs = [vpp.make_batch(ys, uvs, fp2, out=out, width=src_w) for (ys, uvs, out) in sets]
+                for i in range(3):
+                    vpp.run_batch(bs[i % len(bs)], cur_stream)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for i in range(20):
+                    vpp.run_batch(bs[i % len(bs)], cur_stream)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 20
+                others[name] = {"frames_per_s": round(B / (ms * 1e-3), 1), "hbm_frac": round(bytes_per_frame * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            res["config"]["other_resize_types"] = others
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(res), flush=True)
