@@ -70,6 +70,16 @@ def test_all_2pow24_yuv_triples(vpp, oracle):
     assert np.unique(got).size == 256
 
 
+def test_all_2pow24_yuv_triples_hsv_and_formats(vpp, oracle):
+    """Every (Y,U,V) input through HSV -- whose three divisions per pixel run as an in-range refinement chain instead of
+    the compiler's full IEEE sequence: this is the exhaustive check over everything reachable -- and through the
+    Y800 / NV12 / UYVY / YUV444 outputs (x/255 on integers and on multiples of 1/16)."""
+    y, uv = coverage_frame()
+    check(vpp, oracle, y, uv, fourcc=6, planes=MERGED, normalization=True)
+    for fourcc in (0, 3, 4, 5):
+        check(vpp, oracle, y, uv, fourcc=fourcc, planes=MERGED, normalization=True)
+
+
 @pytest.mark.parametrize("rt", [NEAREST, BILINEAR, BICUBIC, AREA])
 @pytest.mark.parametrize("src,dst", [((1920, 1080), (1280, 720)),   # headline, ratio 1.5
                                      ((1080, 608), (480, 360)),     # reference test size, non-dyadic
