@@ -477,8 +477,8 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
     // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel).  dst_w is even; when it
-    // is 4 k + 2 the last thread tile of a row converts its two columns on the generic element-wise path (rows then
-    // start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
+    // is 4 k + 2 they skip the two-column tail of every row and launch_fused adds a tiny element-wise launch for it
+    // (rows then start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
     bool aligned_out = true;
     for (int f = 0; f < n; f++) {
         if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
