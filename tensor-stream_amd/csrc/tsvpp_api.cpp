@@ -326,8 +326,8 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     std::vector<AreaQRow> q;
     if (quantise_area_rows(tab, t.rows, t.taps, q, t.shift)) {
         t.uniform_sum = q[0].sum;
-        for (const AreaQRow &e : q)
-            if (e.sum != q[0].sum) t.uniform_sum = 0;
+        for (const AreaQRow &row : q)
+            if (row.sum != q[0].sum) t.uniform_sum = 0;
         if (hipMalloc((void **)&t.qdev, q.size() * sizeof(AreaQRow)) == hipSuccess &&
             hipMemcpy(t.qdev, q.data(), q.size() * sizeof(AreaQRow), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(t.qdev);
