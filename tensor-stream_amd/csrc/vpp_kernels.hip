@@ -2433,10 +2433,10 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
                 const long resident = (long)d.num_cus * d.persist;
                 dim3 pgrid((unsigned)(total < resident ? total : resident));
-                TSVPP_LAUNCH("vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>", (vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, 2 * lds_bytes);
+                TSVPP_LAUNCH(MODE == M_AREA_UP ? "vpp_bilinear_persistent_kernel<areaup,OUT>" : "vpp_bilinear_persistent_kernel<bilinear,OUT>", (vpp_bilinear_persistent_kernel<MODE == M_AREA_UP, OUT>), pgrid, block, 2 * lds_bytes);
                 return info ? hipSuccess : hipGetLastError();
             }
-            TSVPP_LAUNCH("vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>", (vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes);
+            TSVPP_LAUNCH(MODE == M_AREA_UP ? "vpp_bilinear_kernel<areaup,OUT>" : "vpp_bilinear_kernel<bilinear,OUT>", (vpp_bilinear_kernel<MODE == M_AREA_UP, OUT>), grid, block, lds_bytes);
             return info ? hipSuccess : hipGetLastError();
         }
     } else if constexpr (MODE == M_BICUBIC) {

@@ -18,7 +18,7 @@ def plan(src, dst=(0, 0), rt=N, fourcc=BGR24, planes=0, norm=True, crop=(0, 0, 0
 def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
     p = plan((1920, 1080), (1280, 720), B, pitch=2048)
     assert p["mode"] == "bilinear" and p["out"] == "f32_planar"
-    assert p["kernel"].startswith("vpp_bilinear_kernel<") and (p["shape"], p["rpt"], p["dma"]) == ("32x8", 2, 1)
+    assert p["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>" and (p["shape"], p["rpt"], p["dma"]) == ("32x8", 2, 1)
     assert p["tiles"] == "10x23" and p["frames"] == 64 and p["lds"] <= 40 * 1024
     # whole tile rows per XCD: rows padded to a multiple of 8
     assert p["grid"] == (23 * 64 + 7) // 8 * 8 * 10
@@ -39,7 +39,7 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
     ((1920, 1080), (224, 224), A, "vpp_area_direct_float_kernel<3"),     # 8.57 x 4.82
     ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2"),             # 6.4 x 3.6: one output column per lane
-    ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<MODE==M_AREA_UP"),  # AREA up-scale = the bilinear variant
+    ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_sep_kernel"),
     ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
     ((1920, 1080), (224, 224), C, "vpp_fused_gather_kernel"),
