@@ -54,6 +54,8 @@ def cpu_baseline(spec, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+    if args.tight_pitch:
+        pitch = src_w
     cores = O.host_cores()
     rng = np.random.default_rng(1)
     y = rng.integers(0, 256, (src_h, src_w), dtype=np.uint8)
@@ -94,6 +96,7 @@ def main():
     ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
     ap.add_argument("--per-call", type=int, default=0, help="frames per C-ABI call (default: the whole batch); 1 = the reference's one Convert per frame")
     ap.add_argument("--graph", action="store_true", help="capture a step's calls in a hipGraph and replay it (launch-bound small calls)")
+    ap.add_argument("--tight-pitch", action="store_true", help="source pitch = width instead of width rounded up to 256 bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -124,6 +127,8 @@ def main():
         spec[5] = args.resize
     spec = tuple(spec)
     src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+    if args.tight_pitch:
+        pitch = src_w
     vpp = ts.VideoProcessor(device=dev, max_consumers=8)
     # the one collective of the path: rank 0's colour coefficient block -> every rank (RCCL over xGMI)
     parallel.broadcast_coeffs(vpp, dist)
