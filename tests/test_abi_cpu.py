@@ -168,3 +168,19 @@ def test_no_product_code_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 code = "\n".join(l for l in txt.splitlines() if not l.strip().startswith(("//", "#", "*", "/*")))
                 assert "vpp_oracle" not in code and "from oracle" not in code and "import oracle" not in code, os.path.join(dp, f)
+
+
+def test_product_fails_loudly_without_the_hip_library_or_a_gpu(monkeypatch):
+    """No CPU fallback anywhere on the product path: a missing libtsvpp.so is a RuntimeError naming the build command, and
+    on a box without a GPU the context cannot be created (tsvpp_create returns the HIP error, surfaced as RuntimeError)."""
+    import torch
+    from tensor_stream import _native as N
+    import tensor_stream as ts
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", "/nonexistent/libtsvpp.so")
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        N.lib()
+    monkeypatch.undo()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ts.VideoProcessor(device=0)
