@@ -1,0 +1,138 @@
+"""CPU guards around bench.py -- the one artefact the round is judged on (a NameError in a side leg
+swallowed the JSON line).  Everything here runs without a GPU: the byte accounting, the cpu_baseline leg under every
+flag that changes its inputs, the whole main() flow on the stub engine (TSVPP_BENCH_STUB=1: no kernels, a step is a
+sleep), the --gpus N self-spawn on gloo, and the "not measured" line when fewer GPUs are visible than requested."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_algorithmic_bytes_match_survey_8d():
+    # SURVEY.md 8(d) "Per-config numbers"
+    want = {"headline": 14169600, "c2": 27993600, "c3": 2168832, "c4": 15206400, "c5": 15206400}
+    for name, s in bench.WORKLOADS.items():
+        assert bench.algorithmic_bytes(s[0], s[1], s[3], s[4], s[8]) == want[name], name
+    assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+
+
+def test_touched_bytes_sparse_samplers():
+    W = bench.WORKLOADS
+    # dense samplers touch the whole ROI
+    for name in ("headline", "c2", "c5"):
+        s = W[name]
+        assert bench.touched_bytes(s) == bench.algorithmic_bytes(s[0], s[1], s[3], s[4], s[8]), name
+    # C3: wX == 0 (xF = 5 j + 2): one column per output column, two rows per output row
+    assert bench.touched_bytes(W["c3"]) == 256 * 512 + 2 * 128 * 256 + 256 * 256 * 3 * 4
+    # C4: bicubic at ratio 3 is a point sample: 1/9 of the source
+    assert bench.touched_bytes(W["c4"]) == 3840 * 2160 * 3 // 2 // 9 + 1280 * 720 * 3
+    s = list(W["headline"])
+    s[5] = "NEAREST"
+    assert bench.touched_bytes(tuple(s)) < bench.touched_bytes(W["headline"])
+
+
+@pytest.mark.parametrize("tight", [False, True])
+@pytest.mark.parametrize("rt,norm,planes", [("BILINEAR", True, "PLANAR"), ("AREA", False, "MERGED")])
+def test_cpu_baseline_leg(tight, rt, norm, planes):
+    spec = (320, 240, 512, (0, 0, 0, 0), (160, 120), rt, "BGR24", planes, norm)
+    r = bench.cpu_baseline(spec, budget_s=0.2, tight_pitch=tight)
+    assert r["value"] > 0 and r["unit"] == "frames/s" and r["cores"] >= 1 and r["kind"] == "port"
+    assert r["swscale"] == "unavailable in image"
+
+
+FLAG_SETS = [[], ["--tight-pitch"], ["--workload", "c4"], ["--workload", "c3", "--tight-pitch"], ["--resize", "AREA"],
+             ["--custom", "640x360:320x180:BICUBIC:RGB24:MERGED:0"], ["--per-call", "1"], ["--workload", "c5", "--no-others"]]
+
+
+@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: " ".join(f) or "default")
+def test_main_flow_on_the_stub_engine(flags, capsys, monkeypatch):
+    """The default path of main() (everything but the GPU engine): one well-formed line with roofline + cpu_baseline."""
+    monkeypatch.setenv("TSVPP_BENCH_STUB", "1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    budget = "0.05" if ("c4" in flags or "c5" in flags) else "0.2"
+    assert bench.main(["--steps", "3", "--warmup", "1", "--cpu-budget", budget] + flags) == 0
+    res = _line(capsys.readouterr().out)
+    for k in REQUIRED:
+        assert k in res, k
+    assert res["data"] == "stub" and res["n_gpus"] == 1 and res["steps"] == 3
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert isinstance(rf["touched_bytes"], int) and "traffic_source" in rf
+    assert len(res["timing"]["repeats_ms_per_step"]) == 5
+    assert sorted(res["timing"]["repeats_ms_per_step"])[2] == res["ms_per_step"]  # the median repeat
+    cb = res["cpu_baseline"]
+    assert "error" not in cb and cb["value"] > 0 and cb["swscale"] == "unavailable in image"
+    if not flags:
+        assert res["metric"] == bench.METRIC
+
+
+def test_a_failing_side_leg_cannot_swallow_the_line(capsys, monkeypatch):
+    monkeypatch.setenv("TSVPP_BENCH_STUB", "1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+
+    def boom(*a, **k):
+        raise NameError("name 'args' is not defined")
+
+    monkeypatch.setattr(bench, "cpu_baseline", boom)
+    monkeypatch.setattr(bench, "touched_bytes", boom)
+    monkeypatch.setattr(bench, "lookup_traffic", boom)
+    assert bench.main(["--steps", "2", "--warmup", "0"]) == 0
+    res = _line(capsys.readouterr().out)
+    assert "NameError" in res["cpu_baseline"]["error"] and res["value"] > 0
+    assert "NameError" in res["roofline"]["touched_bytes"]["error"]
+
+
+def test_gpus_2_self_spawn_on_gloo():
+    """`python bench.py --gpus 2` without a torch.distributed environment re-executes itself under
+    torch.distributed.run: rendezvous, barriers, max-over-ranks, ONE rank-0 line with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSVPP_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["per_rank"]["min_frames_per_s"] <= res["per_rank"]["max_frames_per_s"]
+    assert abs(res["value"] - 2 * 64 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3  # whole-job aggregate
+    assert "cpu_baseline" not in res  # rank 0 at N = 1 only
+
+
+def test_gpus_more_than_visible_prints_not_measured():
+    import torch
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    if n == 1:
+        n = 2  # `--gpus 1` never spawns
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TSVPP_BENCH_STUB")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    assert res["value"] is None and res["n_gpus"] == n and res["n_gpus_visible"] < n
+    assert res["status"].startswith("not measured")
+
+
+def test_stale_traffic_entries_are_dropped(tmp_path):
+    p = tmp_path / "t.json"
+    good = {"round": "rXX", "kernel_src_sha": bench.kernel_src_hash(), "frames_per_launch": 64.0, "hbm_bytes_per_launch": 123}
+    p.write_text(json.dumps({"headline": good, "c2": dict(good, kernel_src_sha="0" * 16), "c5": {k: v for k, v in good.items() if k != "kernel_src_sha"}}))
+    assert bench.lookup_traffic("headline", 64.0, str(p))[0] == 123
+    assert bench.lookup_traffic("headline", 32.0, str(p))[0] is None
+    for w in ("c2", "c5", "c3"):
+        tr, why = bench.lookup_traffic(w, 64.0, str(p))
+        assert tr is None and why
