@@ -21,8 +21,14 @@
  *     (include/Common.h:19-24): 0 = OK, negative = VREADER_* code, positive = a
  *     `hipError_t` value (the reference returns `cudaError_t` the same way);
  *   - all work is enqueued on the given stream and is asynchronous; nothing in the
- *     per-frame path allocates, frees or synchronises (the reference does 1-5
- *     cudaMalloc + 0-4 cudaFree per frame, src/VideoProcessor.cpp:94-166);
+ *     per-frame path frees or synchronises, and nothing allocates once the request
+ *     has been seen by tsvpp_prepare_batch (the reference does 1-5 cudaMalloc + 0-4
+ *     cudaFree per frame, src/VideoProcessor.cpp:94-166).  Without a prepare call the
+ *     FIRST conversion of a new AREA scale builds its weight table, and the first
+ *     UYVY / YUV444 conversion behind a resize on a stream sizes that stream's NV12
+ *     scratch buffer (one hipMalloc each; an outgrown buffer is kept until
+ *     tsvpp_destroy, never freed under running work);
+ *   - every entry point leaves the calling thread's current HIP device as it found it;
  *   - output memory is CALLER-allocated and tight: channels*W*H elements of
  *     uint8 (normalization == 0) or float (normalization != 0), layout as the
  *     reference's kernels write it (src/ColorConversion.cu:41-93).
@@ -115,9 +121,19 @@ int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, v
  * (Not in the reference: one 1080p frame is ~2.5 us of HBM time, below a launch.) */
 int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream);
 
-/* Pre-build everything a (params, input size) pair needs (AREA weight tables) so that
- * later tsvpp_convert* calls for it touch no allocator -- e.g. before graph capture. */
+/* Pre-build everything a (params, input size) pair needs so that later tsvpp_convert* calls for it touch no
+ * allocator -- e.g. before hipGraph capture: the AREA weight tables (the reference mallocs, copies and leaks them
+ * per frame, src/Resize.cu:389-406,436-452) and, for UYVY / YUV444 behind a resize, the resized-NV12 scratch of
+ * `stream` sized for calls of up to `n_frames` frames (the reference cudaMallocs that intermediate per frame,
+ * src/Resize.cu:411-416).  tsvpp_prepare == tsvpp_prepare_batch(..., 0, NULL): tables only. */
 int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height);
+int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height, int n_frames, void *stream);
+
+/* roctx ranges around every conversion ("tsvpp_convert n=.. WxH->WxH ..."), the counterpart of the reference's NVTX
+ * ranges (include/Common.h:72-105 PUSH_RANGE/POP_RANGE, src/VideoProcessor.cpp:95; switched on by
+ * Logger::enableNVTX / TensorStreamConverter.enable_nvtx()).  The tracer library (rocprofiler-sdk-roctx or
+ * libroctx64) is looked up at run time; TSVPP_UNSUPPORTED if neither is installed. */
+int tsvpp_enable_markers(tsvpp_ctx *ctx, int on);
 
 /* Colour constants: read the active block, replace it (e.g. with the block received
  * from rank 0), restore the defaults. */

@@ -51,6 +51,12 @@ def lib():
     return _lib
 
 
+def set_exact_index(on):
+    """BILINEAR / AREA-up start index in integers (the HIP kernels' stated behaviour) instead of the reference's float
+    expression, which is exact only while pitch * height <= 2^24 (see bilinear_tap in vpp_oracle.c)."""
+    lib().vpp_oracle_set_exact_index(1 if on else 0)
+
+
 def channels(fourcc):
     return float(lib().vpp_oracle_channels(int(fourcc)))
 

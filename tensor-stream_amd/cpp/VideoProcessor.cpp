@@ -53,6 +53,7 @@ int VideoProcessor::Init(std::shared_ptr<Logger> log, uint8_t maxConsumers, bool
     logger = log;
     if (device < 0) CHECK_STATUS((int)hipGetDevice(&device));
     CHECK_STATUS(tsvpp_create(device, maxConsumers, &ctx));
+    if (logger && logger->enableNVTX) (void)tsvpp_enable_markers(ctx, 1); // roctx ranges; silently absent without a tracer library
     isClosed = false;
     return VREADER_OK;
 }

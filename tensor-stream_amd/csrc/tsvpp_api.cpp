@@ -5,6 +5,7 @@
 // library builds once: the AREA weight tables (reference src/Resize.cu:436-452 mallocs, copies
 // and leaks them per frame).  No per-frame allocation, free or synchronisation.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cfloat>
 #include <cmath>
@@ -12,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -162,9 +164,19 @@ struct tsvpp_ctx {
     int rpt = 2;                    // TSVPP_RPT
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
-    // NV12 intermediates for the two-pass formats, one grow-only buffer per stream
-    std::map<void *, std::pair<uint8_t *, size_t>> scratch;
+    // NV12 intermediates of the two-pass formats (UYVY / YUV444 with a resize): one grow-only slot per stream.  A slot's
+    // mutex is held while BOTH passes of a call are enqueued, so calls that share a stream (typically NULL) cannot
+    // interleave their passes on the shared buffer; a buffer that is outgrown is retired, not freed -- work already
+    // enqueued may still use it and hipFree would synchronise the device -- and released in tsvpp_destroy.
+    struct ScratchSlot {
+        std::mutex mu;
+        uint8_t *buf = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<void *, std::unique_ptr<ScratchSlot>> scratch;
+    std::vector<uint8_t *> retired;
     std::mutex scratch_mu;
+    int markers = 0; // tsvpp_enable_markers: roctx ranges around every conversion (the reference's NVTX ranges)
 };
 
 namespace {
@@ -339,16 +351,81 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     return TSVPP_OK;
 }
 
-int ensure_device(const tsvpp_ctx *ctx) {
-    int cur = -1;
-    hipError_t e = hipGetDevice(&cur);
-    if (e != hipSuccess) return (int)e;
-    if (cur != ctx->device) {
-        e = hipSetDevice(ctx->device);
-        if (e != hipSuccess) return (int)e;
+// Selects the context's device for the duration of one API call and restores the caller's on exit (as torch's
+// CUDAGuard does): a VideoProcessor bound to device k must not change the calling thread's current device.
+struct DeviceGuard {
+    int prev = -1, status = TSVPP_OK;
+    bool switched = false;
+    explicit DeviceGuard(const tsvpp_ctx *ctx) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { status = (int)e; return; }
+        if (prev != ctx->device) {
+            e = hipSetDevice(ctx->device);
+            if (e != hipSuccess) { status = (int)e; return; }
+            switched = true;
+        }
     }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// roctx ranges (the reference brackets Convert with NVTX ranges: include/Common.h:72-105, src/VideoProcessor.cpp:95).
+// The tracer library is looked up at run time -- rocprofv3's SDK flavour first, the legacy roctracer one second --
+// so libtsvpp.so carries no link-time dependency on either.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" }) {
+            void *h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RangeGuard {
+    bool on;
+    RangeGuard(bool enabled, const char *label) : on(enabled && roctx().push) {
+        if (on) roctx().push(label);
+    }
+    ~RangeGuard() {
+        if (on) roctx().pop();
+    }
+};
+
+// The scratch slot of a stream, created on first use; `need` bytes are guaranteed after grow() (caller holds slot->mu).
+tsvpp_ctx::ScratchSlot *scratch_slot(tsvpp_ctx *ctx, void *stream) {
+    std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+    auto &slot = ctx->scratch[stream];
+    if (!slot) slot.reset(new tsvpp_ctx::ScratchSlot());
+    return slot.get();
+}
+int scratch_grow(tsvpp_ctx *ctx, tsvpp_ctx::ScratchSlot *slot, size_t need) {
+    if (slot->bytes >= need) return TSVPP_OK;
+    uint8_t *fresh = nullptr;
+    hipError_t e = hipMalloc((void **)&fresh, need);
+    if (e != hipSuccess) return (int)e;
+    if (slot->buf) {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        ctx->retired.push_back(slot->buf);
+    }
+    slot->buf = fresh;
+    slot->bytes = need;
     return TSVPP_OK;
 }
+size_t scratch_frame_bytes(const Plan &pl) { return (((size_t)pl.dst_w * pl.dst_h * 3 / 2) + 255) & ~(size_t)255; }
+bool needs_scratch(const Plan &pl) { return (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && pl.mode != M_NONE; }
 
 } // namespace
 
@@ -373,10 +450,13 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess) return (int)e;
     if (device < 0 || device >= count) return (int)hipErrorInvalidDevice;
-    e = hipSetDevice(device);
-    if (e != hipSuccess) return (int)e;
     tsvpp_ctx *ctx = new tsvpp_ctx();
     ctx->device = device;
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) {
+        delete ctx;
+        return guard.status;
+    }
     tsvpp_default_coeffs(&ctx->coeffs);
     read_env_knobs(ctx);
     {
@@ -387,7 +467,9 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
         hipStream_t s = nullptr;
         e = hipStreamCreate(&s); // blocking stream, as the reference (src/VideoProcessor.cpp:86)
         if (e != hipSuccess) {
-            tsvpp_destroy(ctx);
+            for (auto &st : ctx->streams)
+                if (st.second) (void)hipStreamDestroy(st.second);
+            delete ctx;
             return (int)e;
         }
         ctx->streams.emplace_back(std::string("empty"), s);
@@ -398,15 +480,18 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
 
 void tsvpp_destroy(tsvpp_ctx *ctx) {
     if (!ctx) return;
-    (void)ensure_device(ctx);
-    for (auto &s : ctx->streams)
-        if (s.second) (void)hipStreamDestroy(s.second);
-    for (auto &sc : ctx->scratch)
-        if (sc.second.first) (void)hipFree(sc.second.first);
+    {
+        DeviceGuard guard(ctx);
+        for (auto &s : ctx->streams)
+            if (s.second) (void)hipStreamDestroy(s.second);
+        for (auto &sc : ctx->scratch)
+            if (sc.second && sc.second->buf) (void)hipFree(sc.second->buf);
+        for (uint8_t *b : ctx->retired) (void)hipFree(b);
     for (auto &a : ctx->area) {
         if (a.second.dev) (void)hipFree(a.second.dev);
         if (a.second.qdev) (void)hipFree(a.second.qdev);
         if (a.second.dev4) (void)hipFree(a.second.dev4);
+    }
     }
     delete ctx;
 }
@@ -451,20 +536,37 @@ size_t tsvpp_out_bytes(const tsvpp_params *p, int in_width, int in_height) {
     return pl.out_bytes;
 }
 
-int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height) {
-    if (!ctx) return TSVPP_ERROR;
+int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height, int n_frames, void *stream) {
+    if (!ctx || n_frames < 0) return TSVPP_ERROR;
     Plan pl;
     int sts = make_plan(p, in_width, in_height, pl);
     if (sts != TSVPP_OK) return sts;
-    sts = ensure_device(ctx);
-    if (sts != TSVPP_OK) return sts;
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable t;
         sts = get_area_table(ctx, pl.xr, t);
         if (sts != TSVPP_OK) return sts;
         sts = get_area_table(ctx, pl.yr, t);
+        if (sts != TSVPP_OK) return sts;
+    }
+    if (needs_scratch(pl) && n_frames > 0) { // the NV12 intermediate of UYVY / YUV444 behind a resize
+        tsvpp_ctx::ScratchSlot *slot = scratch_slot(ctx, stream);
+        std::lock_guard<std::mutex> lk(slot->mu);
+        sts = scratch_grow(ctx, slot, scratch_frame_bytes(pl) * (size_t)n_frames);
     }
     return sts;
+}
+
+int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height) {
+    return tsvpp_prepare_batch(ctx, p, in_width, in_height, 0, nullptr);
+}
+
+int tsvpp_enable_markers(tsvpp_ctx *ctx, int on) {
+    if (!ctx) return TSVPP_ERROR;
+    if (on && !roctx().push) return TSVPP_UNSUPPORTED; // no roctx library on this machine
+    ctx->markers = on ? 1 : 0;
+    return TSVPP_OK;
 }
 
 int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
@@ -476,23 +578,26 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
-    // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel).  dst_w is even; when it
-    // is 4 k + 2 they skip the two-column tail of every row and launch_fused adds a tiny element-wise launch for it
-    // (rows then start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
-    bool aligned_out = true;
+    // dst_w is even; when it is 4 k + 2 the vector-store kernels skip the two-column tail of every row and launch_fused adds
+    // a tiny element-wise launch for it (rows then start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
+    // (alignment is decided per launch group of TSVPP_MAX_BATCH frames below: one odd pointer does not push the
+    // whole batch onto the element-wise kernel)
     for (int f = 0; f < n; f++) {
         if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
         if (in[f].width != in[0].width || in[f].height != in[0].height) return TSVPP_UNSUPPORTED;
         if ((in[f].pitch_y ? in[f].pitch_y : in[f].width) != pitch_y) return TSVPP_UNSUPPORTED;
         if ((in[f].pitch_uv ? in[f].pitch_uv : in[f].width) != pitch_uv) return TSVPP_UNSUPPORTED;
-        if (((uintptr_t)outs[f] & 15) != 0) aligned_out = false;
     }
-    sts = ensure_device(ctx);
-    if (sts != TSVPP_OK) return sts;
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
+    char label[96];
+    if (ctx->markers)
+        std::snprintf(label, sizeof(label), "tsvpp_convert n=%d %dx%d->%dx%d mode=%d fourcc=%d stream=%p", n, pl.src_w, pl.src_h, pl.dst_w, pl.dst_h,
+                      (int)pl.mode, pl.fourcc, stream);
+    RangeGuard range(ctx->markers != 0, label);
 
     LaunchDesc d;
     fill_desc(ctx, pl, pitch_y, pitch_uv, d);
-    bool vec = aligned_out;
     if (pl.mode == M_AREA_DOWN) {
         AreaTable tx, ty;
         sts = get_area_table(ctx, pl.xr, tx);
@@ -532,25 +637,18 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
     uint8_t *scratch = nullptr;
     size_t frame_scratch = 0;
-    if (two_pass && pl.mode != M_NONE) {
-        frame_scratch = (((size_t)pl.dst_w * pl.dst_h * 3 / 2) + 255) & ~(size_t)255;
-        const size_t need = frame_scratch * (size_t)n;
-        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
-        auto &slot = ctx->scratch[stream];
-        if (slot.second < need) { // grow-only; hipFree synchronises, so the old buffer is idle when released
-            if (slot.first) (void)hipFree(slot.first);
-            slot = { nullptr, 0 };
-            hipError_t e = hipMalloc((void **)&slot.first, need);
-            if (e != hipSuccess) return (int)e;
-            slot.second = need;
-        }
-        scratch = slot.first;
+    std::unique_lock<std::mutex> scratch_lock; // held until both passes of this call are enqueued
+    if (needs_scratch(pl)) {
+        frame_scratch = scratch_frame_bytes(pl);
+        tsvpp_ctx::ScratchSlot *slot = scratch_slot(ctx, stream);
+        scratch_lock = std::unique_lock<std::mutex>(slot->mu);
+        // sized by tsvpp_prepare_batch: then this is a no-op; otherwise the first call for a (size, n) pays one hipMalloc
+        sts = scratch_grow(ctx, slot, frame_scratch * (size_t)n);
+        if (sts != TSVPP_OK) return sts;
+        scratch = slot->buf;
     }
     const OutKind out_kind = pl.out;
-    if (two_pass) {
-        vec = true; // scratch frames are 256-byte aligned
-        if (d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
-    }
+    if (two_pass && d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
         FrameTable t;
@@ -565,6 +663,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
             t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
         }
         d.n_frames = cnt;
+        // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel); scratch frames are
+        // 256-byte aligned.
+        bool vec = true;
+        if (!two_pass)
+            for (int f = 0; f < cnt; f++)
+                if (((uintptr_t)outs[base + f] & 15) != 0) vec = false;
         if (!(two_pass && pl.mode == M_NONE)) {
             hipError_t e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;

@@ -34,7 +34,7 @@ class Coeffs(ctypes.Structure):
 
 # every symbol include/tsvpp.h declares (tests check that the library exports all of them)
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
-           "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_get_coeffs",
+           "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs",
            "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version"]
 
 _lib = None
@@ -63,6 +63,8 @@ def lib():
     L.tsvpp_convert.argtypes = [vp, pn, pp, vp, vp]
     L.tsvpp_convert_batch.argtypes = [vp, i32, pn, pp, ctypes.POINTER(vp), vp]
     L.tsvpp_prepare.argtypes = [vp, pp, i32, i32]
+    L.tsvpp_prepare_batch.argtypes = [vp, pp, i32, i32, i32, vp]
+    L.tsvpp_enable_markers.argtypes = [vp, i32]
     L.tsvpp_get_coeffs.argtypes = [vp, ctypes.POINTER(Coeffs)]
     L.tsvpp_set_coeffs.argtypes = [vp, ctypes.POINTER(Coeffs)]
     L.tsvpp_default_coeffs.argtypes = [ctypes.POINTER(Coeffs)]
@@ -74,7 +76,7 @@ def lib():
     L.tsvpp_version.argtypes = []
     L.tsvpp_version.restype = ctypes.c_char_p
     for f in ("tsvpp_create", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_convert", "tsvpp_convert_batch",
-              "tsvpp_prepare", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern", "tsvpp_describe"):
+              "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern", "tsvpp_describe"):
         getattr(L, f).restype = i32
     _lib = L
     return L

@@ -115,6 +115,7 @@ class TensorStreamConverter:
         self._ring = None
         self._stop = threading.Event()
         self._logs = (LogsLevel.NONE, LogsType.CONSOLE)
+        self._markers = False
 
     # ---- lifecycle -------------------------------------------------------------------------------
     def initialize(self, repeat_number=1):
@@ -123,6 +124,8 @@ class TensorStreamConverter:
             try:
                 self._source = open_source(self.stream_url)
                 self._vpp = VideoProcessor(device=self.cuda_device, max_consumers=self.max_consumers)
+                if self._markers:
+                    self._vpp.enable_markers(True)
                 self._ring = FrameRing(self.buffer_size)
                 self._stop.clear()
                 self.fps = self._source.fps_num / self._source.fps_den
@@ -137,7 +140,12 @@ class TensorStreamConverter:
         self._logs = (level, log_type)
 
     def enable_nvtx(self):
-        pass  # roctx ranges would go here; the reference's NVTX tracer has no ROCm counterpart in this build
+        """Reference: NVTX ranges around the pipeline stages (tensor_stream/tensor_stream.py enable_nvtx,
+        include/Common.h:72-105).  Here: roctx ranges around every conversion, visible to rocprofv3 --marker-trace.
+        May be called before or after initialize(), like the reference's."""
+        self._markers = True
+        if self._vpp is not None:
+            self._vpp.enable_markers(True)
 
     def set_timeout(self, timeout):
         self._timeout = None if timeout is None else float(timeout)

@@ -105,9 +105,17 @@ class VideoProcessor:
         N.check(self._lib.tsvpp_out_dims(ctypes.byref(p), in_w, in_h, ctypes.byref(w), ctypes.byref(h)))
         return w.value, h.value
 
-    def prepare(self, params, in_w, in_h):
+    def prepare(self, params, in_w, in_h, n_frames=0, stream=None):
+        """Pre-builds what the request needs (AREA tables; with n_frames > 0 also the UYVY / YUV444 scratch of `stream`,
+        default torch's current stream) so that later conversions allocate nothing -- e.g. before graph capture."""
         p = params.parameters if isinstance(params, FrameParameters) else params
-        N.check(self._lib.tsvpp_prepare(self._ctx, ctypes.byref(p), in_w, in_h))
+        if n_frames and stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.tsvpp_prepare_batch(self._ctx, ctypes.byref(p), in_w, in_h, int(n_frames), stream or 0))
+
+    def enable_markers(self, on=True):
+        """roctx ranges around every conversion (the reference's NVTX ranges); RuntimeError if no roctx library exists."""
+        N.check(self._lib.tsvpp_enable_markers(self._ctx, 1 if on else 0))
 
     def consumer_stream(self, name):
         s = ctypes.c_void_p()
@@ -118,9 +126,22 @@ class VideoProcessor:
         ow, oh = self.out_dims(p, in_w, in_h)
         shape = output_shape(p, ow, oh)
         dtype = torch.float32 if (p.normalization or p.fourcc == FourCC.HSV.value) else torch.uint8
-        if n is not None:
-            shape = (n,) + tuple(shape)
-        return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+        if n is None:
+            return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+        # batch: every frame must start 16-byte aligned or its launch group falls back to the element-wise kernel
+        # (uint8 frames of e.g. 250 x 250 x 3 bytes are not a multiple of 16): pad the frame stride, return a view
+        numel = 1
+        for d in shape:
+            numel *= d
+        esz = 4 if dtype == torch.float32 else 1
+        stride = (numel * esz + 15) // 16 * 16 // esz
+        flat = torch.empty(n * stride, dtype=dtype, device=f"cuda:{self.device}")
+        inner = []
+        acc = 1
+        for d in reversed(shape):
+            inner.insert(0, acc)
+            acc *= d
+        return flat.as_strided((n,) + tuple(shape), (stride,) + tuple(inner))
 
     @staticmethod
     def _frame(y, uv, width, height):

@@ -157,3 +157,17 @@ def test_two_op_division_by_255_is_exact_for_sixteenths():
     for k in range(255 * 16 + 1):
         x = Fr(k, 16)
         assert fl32(x * hi + fl32(x * lo)) == fl32(x / 255), k
+
+
+def test_exact_index_mode_equals_the_float_index_below_2pow24(oracle):
+    """vpp_oracle_set_exact_index: the integer start index equals the reference's float expression (src/Resize.cu:6)
+    wherever that is exact, i.e. for every frame with pitch * height <= 2^24 -- all BASELINE sizes (4K: 3840 * 2160 = 8.3 M)."""
+    for (w, h, dst, rt) in [(1920, 1080, (1280, 720), 1), (3840, 2160, (1280, 720), 1), (640, 360, (1280, 720), 3), (1080, 608, (480, 360), 1)]:
+        y, uv = synth_nv12(w, h, seed=w + rt)
+        a, _, _ = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=oracle.NV12, nthreads=8)
+        oracle.set_exact_index(True)
+        try:
+            b, _, _ = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=oracle.NV12, nthreads=8)
+        finally:
+            oracle.set_exact_index(False)
+        assert np.array_equal(a, b), (w, h, dst, rt)
