@@ -127,6 +127,27 @@ bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_
     return remember(true);
 }
 
+// Is every BICUBIC weight of this request a multiple of 1/16?  (ratios 1.5, 2, 2.5, 4, 0.5, 1.25, 2.25 ...: then the
+// reference's fp64 evaluation is exact and the integer kernel of vpp_bicubic_int.hip reproduces it bit for bit)
+bool bicubic_weights_dyadic(int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
+    struct Memo { int dw, dh, sw, sh; bool res; };
+    static thread_local Memo memo = { 0, 0, 0, 0, false };
+    if (memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
+    auto remember = [&](bool r) { memo = Memo{ dst_w, dst_h, src_w, src_h, r }; return r; };
+    for (int axis = 0; axis < 2; axis++) {
+        const int n = axis ? dst_h : dst_w, lim = axis ? src_h : src_w;
+        const float r = axis ? yr : xr;
+        for (int o = 0; o < n; o++) { // the chroma grid uses indices 0 .. n/2-1, a subset
+            int p;
+            double w;
+            bicubic_axis(o, r, lim, p, w);
+            const double s = w * 16.0;
+            if (s != std::floor(s)) return remember(false);
+        }
+    }
+    return remember(true);
+}
+
 struct Plan {
     Mode mode = M_NONE;
     OutKind out = O_U8_MERGED;
@@ -137,6 +158,7 @@ struct Plan {
     int swap_rb = 0;
     size_t out_bytes = 0;
     int point_kind = PK_NONE;
+    int bic_dyadic = 0;
     int fourcc = TSVPP_RGB24;
     bool f32 = false;
 };
@@ -158,10 +180,11 @@ struct tsvpp_ctx {
     float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
     float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
+    int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
     int area_cols = 1;              // TSVPP_AREA_COLS
-    int rpt = 2;                    // TSVPP_RPT
+    int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     std::mutex area_mu;
     // NV12 intermediates of the two-pass formats (UYVY / YUV444 with a resize): one grow-only slot per stream.  A slot's
@@ -222,6 +245,7 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     if (pl.mode == M_NEAREST) pl.point_kind = PK_NEAREST;
     else if ((pl.mode == M_BILINEAR || pl.mode == M_BICUBIC) && all_weights_zero(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h))
         pl.point_kind = pl.mode == M_BILINEAR ? PK_BILINEAR0 : PK_BICUBIC0;
+    pl.bic_dyadic = (pl.mode == M_BICUBIC && pl.point_kind == PK_NONE && bicubic_weights_dyadic(pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h)) ? 1 : 0;
     pl.fourcc = p->fourcc;
     switch (p->fourcc) {
     case TSVPP_RGB24: pl.swap_rb = 0; break;
@@ -259,6 +283,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
@@ -292,6 +317,8 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_direct_min = ctx->area_direct_min;
     d.area_direct_fmin = ctx->area_direct_fmin;
     d.bicubic_sep = ctx->bicubic_sep;
+    d.bicubic_int_pref = ctx->bicubic_int;
+    d.bic_dyadic = pl.bic_dyadic;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;

@@ -1,0 +1,845 @@
+// vpp_device.h -- device-side building blocks shared by the kernel translation units (vpp_kernels.hip,
+// vpp_bicubic_int.hip): source readers, samplers, the colour back end (color_store_tile), the work decomposition
+// (decode_tile), footprints and LDS staging.  Product code -- never includes anything from oracle/.
+//
+// Arithmetic contract: every float/double operation is a single IEEE-754 operation in the order the reference's source
+// text gives it -- NO fused multiply-add (contraction is off in every file that includes this header), truncating
+// float->int conversions, round-half-away for the bicubic stage.  The only fma()s are explicit ones.
+#pragma once
+#include "vpp_kernels.h"
+#include "vpp_axis.h"
+
+#pragma clang fp contract(off)
+
+namespace tsvpp {
+
+// Thread tile: 2 output rows x 4 output columns (= one resized-chroma row of 2 pairs).
+// Workgroup: tx x ty thread tiles (launch-time choice, tx a power of two, tx*ty <= 256), i.e.
+// (4*tx) x (2*ty) output pixels; 32 x 8 threads -> 128 x 16 pixels is the default.
+constexpr int PXW = 4, PXH = 2;
+constexpr int MAX_THREADS = 256;
+constexpr int NUM_XCD = 8;
+
+// Two floats per lane: gfx950 executes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on such pairs in
+// the time of one scalar op, and each half is an independent IEEE operation -- results are
+// bit-identical to the scalar sequence.  The VPP kernels are VALU-issue bound before they are
+// HBM bound, so the blend and colour arithmetic is written on horizontally adjacent pixel pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ----------------------------------------------------------------------------------------------
+// Source access.  Two readers with the same interface:
+//   GlobalSrc -- byte gathers straight from global memory (fallback: huge footprints, odd widths).
+//                Coordinates are clamped into the logical source so that no input can fault; for
+//                every valid (even-sized) request the clamps never fire.
+//   LdsSrc    -- the workgroup's source footprint staged in LDS by 16-byte coalesced loads.
+struct GlobalSrc {
+    const uint8_t *y, *uv;
+    int py, puv; // pitches in bytes
+    int w, h;    // logical source size in luma pixels
+    __device__ __forceinline__ int Y(int row, int col) const {
+        row = min(max(row, 0), h - 1);
+        col = min(max(col, 0), w - 1);
+        return y[(uint32_t)row * (uint32_t)py + (uint32_t)col];
+    }
+    // col is a BYTE column of the interleaved UV plane
+    __device__ __forceinline__ int UV(int row, int col) const {
+        row = min(max(row, 0), (h >> 1) - 1);
+        col = min(max(col, 0), w - 1);
+        return uv[(uint32_t)row * (uint32_t)puv + (uint32_t)col];
+    }
+};
+
+// One staged plane: LDS row r holds source row (y0 + r); because global loads are 16-byte aligned
+// and the pitch need not be, each row is shifted by its own misalignment (m0 + r*pm) & 15.
+struct LdsPlane {
+    const uint8_t *base;
+    int x0, y0; // source byte-column / row of the footprint origin
+    int lp;     // LDS row pitch in bytes (multiple of 16)
+    int m0, pm; // misalignment of row 0, pitch & 15
+    __device__ __forceinline__ int at(int row, int col) const {
+        const int r = row - y0;
+        return base[r * lp + ((m0 + r * pm) & 15) + (col - x0)];
+    }
+};
+struct LdsSrc {
+    LdsPlane py_, puv_;
+    int w, h;
+    __device__ __forceinline__ int Y(int row, int col) const { return py_.at(row, col); }
+    __device__ __forceinline__ int UV(int row, int col) const { return puv_.at(row, col); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Bilinear blend, reference src/Resize.cu:17-23: four products summed left to right, truncated.
+__device__ __forceinline__ int bilerp(int A, int B, int C, int D, float wx, float wy) {
+    float omx = 1.0f - wx, omy = 1.0f - wy;
+    float t1 = ((float)A * omx) * omy;
+    float t2 = ((float)B * wx) * omy;
+    float t3 = ((float)C * wy) * omx;
+    float t4 = (float)D * (wx * wy);
+    float s = t1 + t2;
+    s = s + t3;
+    s = s + t4;
+    return (int)s;
+}
+
+// Keys cubic, a = -0.75 (src/Resize.cu:45-50).  pow(w,2), pow(w,3) are the exact square and the
+// correctly rounded cube: w has <= 24 significant bits (oracle/pow_pin.c).
+__device__ __forceinline__ void cubic_coeffs(double w, double c[4]) {
+    const double a = -0.75;
+    double w2 = w * w, w3 = w2 * w;
+    c[0] = (a * w - (2 * a) * w2) + a * w3;
+    c[1] = (1 - (a + 3) * w2) + (a + 2) * w3;
+    c[2] = ((-a) * w + (2 * a + 3) * w2) - (a + 2) * w3;
+    c[3] = a * w2 - a * w3;
+}
+__device__ __forceinline__ int clamp255(int v) { return max(min(v, 255), 0); }
+__device__ __forceinline__ int cubic4(const double c[4], int p0, int p1, int p2, int p3) {
+    double a0 = c[0] * (double)p0, a1 = c[1] * (double)p1, a2 = c[2] * (double)p2, a3 = c[3] * (double)p3;
+    double s = a0 + a1;
+    s = s + a2;
+    s = s + a3;
+    return clamp255((int)round(s));
+}
+// Mixed-precision form of cubic4.  The reference's value is round(s64) of a 4-term fp64 sum that is
+// at most a few hundred in magnitude; an fp32 evaluation s32 of the same sum differs from it by far
+// less than CUBIC_DELTA (coefficient rounding 255*4*6e-8, products and sums < 2e-4 in total), so
+// wherever s32 is further than CUBIC_DELTA from a half-integer round(s32) == round(s64) and the
+// fp64 arithmetic (half rate, plus the coefficient polynomials) is skipped.  The few lanes that are
+// close to a tie recompute exactly as the reference does.  `w` is the weight as a float: it IS
+// exact (fraction of a float coordinate).
+constexpr float CUBIC_DELTA = 5e-4f;
+__device__ __forceinline__ void cubic_coeffs_f(float w, float c[4]) {
+    const float a = -0.75f;
+    const float w2 = w * w, w3 = w2 * w;
+    c[0] = (a * w - (2 * a) * w2) + a * w3;
+    c[1] = (1 - (a + 3) * w2) + (a + 2) * w3;
+    c[2] = ((-a) * w + (2 * a + 3) * w2) - (a + 2) * w3;
+    c[3] = a * w2 - a * w3;
+}
+__device__ __forceinline__ int cubic4_mixed(float w, const float cf[4], int p0, int p1, int p2, int p3) {
+    const float s = ((cf[0] * (float)p0 + cf[1] * (float)p1) + cf[2] * (float)p2) + cf[3] * (float)p3;
+    const float fl = floorf(s);
+    if (fabsf((s - fl) - 0.5f) < CUBIC_DELTA) { // within reach of a tie: the reference's fp64 arithmetic decides
+        double c[4];
+        cubic_coeffs((double)w, c);
+        return cubic4(c, p0, p1, p2, p3);
+    }
+    return clamp255((int)fl + ((s - fl) > 0.5f ? 1 : 0)); // round to nearest; negative sums clamp to 0 either way
+}
+
+// Two 4-tap sums at once on float pairs (packed VALU).  Rounding by the 1.5 * 2^23 trick (nearest
+// even -- it differs from the reference's half-away rule only AT a tie, and anything within
+// CUBIC_DELTA of a tie is recomputed exactly); results stay integer-valued floats, clamped.
+__device__ __forceinline__ f2 cubic4_pair(float w0, float w1, const float c0[4], const float c1[4], const f2 p[4], const int q0[4], const int q1[4]) {
+    f2 s = ((f2){ c0[0], c1[0] } * p[0] + (f2){ c0[1], c1[1] } * p[1]) + (f2){ c0[2], c1[2] } * p[2];
+    s = s + (f2){ c0[3], c1[3] } * p[3];
+    const f2 magic = { 12582912.0f, 12582912.0f };
+    f2 r = (s + magic) - magic;
+    const f2 dd = s - r;
+    r.x = __builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f);
+    r.y = __builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);
+    const bool tie0 = fabsf(dd.x) > 0.5f - CUBIC_DELTA, tie1 = fabsf(dd.y) > 0.5f - CUBIC_DELTA;
+    if (tie0 || tie1) { // one (rarely taken) branch for the pair
+        if (tie0) {
+            double c[4];
+            cubic_coeffs((double)w0, c);
+            r.x = (float)cubic4(c, q0[0], q0[1], q0[2], q0[3]);
+        }
+        if (tie1) {
+            double c[4];
+            cubic_coeffs((double)w1, c);
+            r.y = (float)cubic4(c, q1[0], q1[1], q1[2], q1[3]);
+        }
+    }
+    return r;
+}
+
+// Tap offsets with the reference's edge rule (src/Resize.cu:32-43): the +1 AND +2 taps collapse
+// onto the centre when either would leave the plane; the -1 tap collapses at the low edge.
+__device__ __forceinline__ void bicubic_offsets(int p, int step, int limit, int &lo, int &hi) {
+    hi = step;
+    lo = step;
+    if (p + step >= limit) hi = 0;
+    if (p + hi * 2 >= limit) hi = 0;
+    if (p - step < 0) lo = 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Samplers: resized LUMA at output pixel (i, j) and resized CHROMA pair at chroma-grid (ci, cj).
+// The chroma grid reuses the luma formulas on its own indices (the reference runs the same
+// thread for both, guarded by i < H/2 && j < W/2).
+
+template <int MODE, class S>
+__device__ __forceinline__ int sample_luma(const S &s, const LaunchDesc &d, int i, int j) {
+    if constexpr (MODE == M_NONE) {
+        return s.Y(i, j);
+    } else if constexpr (MODE == M_NEAREST) { // src/Resize.cu:249-258
+        int y = (int)(d.yr * (float)i), x = (int)(d.xr * (float)j);
+        return s.Y(y, x);
+    } else if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
+        int x, y;
+        float wx, wy;
+        if constexpr (MODE == M_BILINEAR) {
+            bilinear_axis(j, d.xr, s.w, x, wx);
+            bilinear_axis(i, d.yr, s.h, y, wy);
+        } else {
+            areaup_axis(j, d.xr, x, wx);
+            areaup_axis(i, d.yr, y, wy);
+        }
+        int xd = (x + 1 >= s.w) ? 0 : 1;
+        int y2 = (y + 1 >= s.h) ? y : y + 1;
+        return bilerp(s.Y(y, x), s.Y(y, x + xd), s.Y(y2, x), s.Y(y2, x + xd), wx, wy) & 0xff;
+    } else if constexpr (MODE == M_BICUBIC) {
+        int x, y;
+        double wx, wy;
+        bicubic_axis(j, d.xr, s.w, x, wx);
+        bicubic_axis(i, d.yr, s.h, y, wy);
+        int xl, xh, yl, yh;
+        bicubic_offsets(x, 1, s.w, xl, xh);
+        bicubic_offsets(y, 1, s.h, yl, yh);
+        const float wxf = (float)wx, wyf = (float)wy; // exact
+        float cx[4], cy[4];
+        cubic_coeffs_f(wxf, cx);
+        cubic_coeffs_f(wyf, cy);
+        const int rows[4] = { y - yl, y, y + yh, y + 2 * yh };
+        int b[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            b[r] = cubic4_mixed(wxf, cx, s.Y(rows[r], x - xl), s.Y(rows[r], x), s.Y(rows[r], x + xh), s.Y(rows[r], x + 2 * xh));
+        return cubic4_mixed(wyf, cy, b[0], b[1], b[2], b[3]);
+    } else { // M_AREA_DOWN, src/Resize.cu:160-178, 186-201
+        int y = (int)(d.yr * (float)i), x = (int)(d.xr * (float)j);
+        const float *px = d.patx + (j % d.nx) * d.rx;
+        const float *py = d.paty + (i % d.ny) * d.ry;
+        float sum = 0.f, div = 0.f;
+        for (int a = 0; a < d.ry; a++) {
+            float wy = py[a];
+            for (int b = 0; b < d.rx; b++) {
+                float wgt = px[b] * wy;
+                div = div + wgt;
+                float v = (float)s.Y(y + a, x + b) * wgt;
+                sum = sum + v;
+            }
+        }
+        sum = sum / div;
+        return (int)sum & 0xff;
+    }
+}
+
+template <int MODE, class S>
+__device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, int ci, int cj, int &U, int &V) {
+    const int ch = s.h >> 1; // rows of the UV plane
+    if constexpr (MODE == M_NONE) {
+        U = s.UV(ci, 2 * cj);
+        V = s.UV(ci, 2 * cj + 1);
+    } else if constexpr (MODE == M_NEAREST) { // src/Resize.cu:262-265
+        int y = (int)(d.yr * (float)ci), x = (int)(d.xr * (float)cj);
+        U = s.UV(y, 2 * x);
+        V = s.UV(y, 2 * x + 1);
+    } else if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) { // src/Resize.cu:308-309, 236-237
+        int x, y;
+        float wx, wy;
+        if constexpr (MODE == M_BILINEAR) {
+            bilinear_axis(cj, d.xr, s.w, x, wx);
+            bilinear_axis(ci, d.yr, s.h, y, wy);
+        } else {
+            areaup_axis(cj, d.xr, x, wx);
+            areaup_axis(ci, d.yr, y, wy);
+        }
+        int xu = 2 * x, xv = 2 * x + 1;
+        int du = (xu + 2 >= s.w) ? 0 : 2;
+        int dv = (xv + 2 >= s.w) ? 0 : 2;
+        int y2 = (y + 1 >= ch) ? y : y + 1;
+        U = bilerp(s.UV(y, xu), s.UV(y, xu + du), s.UV(y2, xu), s.UV(y2, xu + du), wx, wy) & 0xff;
+        V = bilerp(s.UV(y, xv), s.UV(y, xv + dv), s.UV(y2, xv), s.UV(y2, xv + dv), wx, wy) & 0xff;
+    } else if constexpr (MODE == M_BICUBIC) { // src/Resize.cu:353-354
+        int x, y;
+        double wx, wy;
+        bicubic_axis(cj, d.xr, s.w, x, wx);
+        bicubic_axis(ci, d.yr, s.h, y, wy);
+        int yl, yh;
+        bicubic_offsets(y, 1, ch, yl, yh);
+        const float wxf = (float)wx, wyf = (float)wy; // exact
+        float cx[4], cy[4];
+        cubic_coeffs_f(wxf, cx);
+        cubic_coeffs_f(wyf, cy);
+        const int rows[4] = { y - yl, y, y + yh, y + 2 * yh };
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            int xc = 2 * x + comp, xl, xh;
+            bicubic_offsets(xc, 2, s.w, xl, xh);
+            int b[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                b[r] = cubic4_mixed(wxf, cx, s.UV(rows[r], xc - xl), s.UV(rows[r], xc), s.UV(rows[r], xc + xh), s.UV(rows[r], xc + 2 * xh));
+            int v = cubic4_mixed(wyf, cy, b[0], b[1], b[2], b[3]);
+            if (comp == 0) U = v; else V = v;
+        }
+    } else { // M_AREA_DOWN, src/Resize.cu:204-210: same x, y and the SAME weight rows, stride 2
+        int y = (int)(d.yr * (float)ci), x = (int)(d.xr * (float)cj);
+        const float *px = d.patx + (cj % d.nx) * d.rx;
+        const float *py = d.paty + (ci % d.ny) * d.ry;
+        float su = 0.f, sv = 0.f, div = 0.f;
+        for (int a = 0; a < d.ry; a++) {
+            float wy = py[a];
+            for (int b = 0; b < d.rx; b++) {
+                float wgt = px[b] * wy;
+                div = div + wgt;
+                float vu = (float)s.UV(y + a, 2 * x + 2 * b) * wgt;
+                float vv = (float)s.UV(y + a, 2 * x + 2 * b + 1) * wgt;
+                su = su + vu;
+                sv = sv + vv;
+            }
+        }
+        su = su / div;
+        sv = sv / div;
+        U = (int)su & 0xff;
+        V = (int)sv & 0xff;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Colour back end shared by every kernel.  Inputs are the resized samples as integer-valued floats:
+// luma Yf[2][4] and one (U, V) pair per 2x2 block.  BT.601 limited range, reference
+// src/ColorConversion.cu:23-38:
+//     Yv = max(0, Y - 16) * 1.164;  R = (int)(Yv + (1.596 (V-128) + 0.5)) ... min 255, max 0.
+// (int)x truncates toward zero == trunc(x); the clamp is done on the truncated float.
+
+template <int OUT> struct OutT { using type = uint8_t; };
+template <> struct OutT<O_F32_PLANAR> { using type = float; };
+template <> struct OutT<O_F32_MERGED> { using type = float; };
+template <> struct OutT<O_NV12_F32> { using type = float; };
+template <> struct OutT<O_Y800_F32> { using type = float; };
+template <> struct OutT<O_HSV_F32> { using type = float; };
+template <int OUT> constexpr bool kLumaOnly = (OUT == O_Y800_U8 || OUT == O_Y800_F32);
+
+// Per-block chroma terms: t0 / t2 are added to luma for the first / third stored channel
+// (R,B or B,R when swapped), tg for green.
+__device__ __forceinline__ void chroma_terms(float Uf, float Vf, const tsvpp_coeffs &k, int swap_rb, float &t0, float &tg, float &t2) {
+    f2 uv = { Uf, Vf };
+    uv = uv - (f2){ k.c_offset, k.c_offset };
+    f2 br = uv * (f2){ k.u_to_b, k.v_to_r };
+    br = br + (f2){ k.round_bias, k.round_bias }; // { 2.018 (U-128) + .5, 1.596 (V-128) + .5 }
+    f2 g = uv * (f2){ k.u_to_g, k.v_to_g };        // u_to_g < 0: g.y + g.x == -0.813 (V-128) - 0.391 (U-128)
+    float gv = g.y + g.x;
+    tg = gv + k.round_bias;
+    t0 = swap_rb ? br.x : br.y;
+    t2 = swap_rb ? br.y : br.x;
+}
+
+__device__ __forceinline__ f2 trunc_clamp255(f2 v) {
+    f2 r;
+    r.x = __builtin_amdgcn_fmed3f(__builtin_truncf(v.x), 0.0f, 255.0f);
+    r.y = __builtin_amdgcn_fmed3f(__builtin_truncf(v.y), 0.0f, 255.0f);
+    return r;
+}
+
+// v / 255 for an integer-valued v in [0, 255], correctly rounded (== the reference's IEEE
+// `/= 255`; all 256 inputs are checked by the tests): 1/255 = hi + lo, e = v*lo, q = fma(v, hi, e).
+// Two (packed) VALU ops instead of the ~10-instruction v_div_scale/fmas/fixup sequence; a zero of
+// either sign yields +0.0 like the reference's int -> float conversion.
+__device__ __forceinline__ f2 norm255(f2 v) {
+    const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;
+    f2 e = v * (f2){ lo, lo };
+    f2 q;
+    q.x = __builtin_fmaf(v.x, hi, e.x);
+    q.y = __builtin_fmaf(v.y, hi, e.y);
+    return q;
+}
+
+// a / b, correctly rounded, for operands whose quotient needs no scaling: this is the refinement chain of the
+// compiler's own IEEE fp32 division (rcp, one Newton step on the reciprocal, two on the quotient) without the
+// v_div_scale / v_div_fixup bracket that only matters for denormal, overflowing or special operands.  HSV
+// operands are k/255 fractions and hues in [-60, 420] over deltas >= 1/255; lanes with b == 0 produce NaN
+// here and are discarded by the caller's selects, as their IEEE counterparts are.
+__device__ __forceinline__ float div_inrange(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+// Normalised RGB -> HSV in [0, 1], the reference's RGBMergedToHSVMerged (src/ColorConversion.cu:235-278),
+// branch-free: the hue sector is chosen with selects, every operation keeps its place and its IEEE
+// rounding.
+__device__ __forceinline__ void hsv_pixel(float R, float G, float B, float &H, float &S, float &V) {
+    const float mn = __builtin_fminf(__builtin_fminf(R, G), B), mx = __builtin_fmaxf(__builtin_fmaxf(R, G), B);
+    const float delta = mx - mn;
+    V = mx;
+    const float q = div_inrange(mn, mx);
+    S = (mx != 0.0f) ? 1.0f - q : 0.0f;
+    const bool r = (R == mx), g = (G == mx);
+    const float diff = r ? G - B : (g ? B - R : R - G);
+    const float off = r ? (G < B ? 360.0f : 0.0f) : (g ? 120.0f : 240.0f);
+    float h = 60.0f * diff;
+    h = div_inrange(h, delta);
+    h = h + off;
+    if (h < 0.0f) h = h + 360.0f;
+    h = div_inrange(h, 360.0f);
+    H = (mx == mn) ? 0.0f : h;
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+// Output store policy (LaunchDesc::nt_stores): 0 plain, 1 non-temporal, 2 `sc1` write-through.  The
+// output is written once and never re-read by the kernel, so it should not displace the input
+// lines in L2: measured on MI355X (tools/ab.sh TSVPP_NT=0/1/2) non-temporal stores gain 3-20 % on
+// the resize kernels, `sc1` 14 % on the colour-only fp32 kernel (25 MB written per 3 MB read) but
+// lose 36 % on 4-byte uint8 stores (each becomes its own fabric write).  launch_fused picks
+// accordingly; TSVPP_NT overrides.
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float e, int nt) {
+    vf4 v = { a, b, c, e };
+    if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if (nt == 1) __builtin_nontemporal_store(v, (vf4 *)p);
+    else *(vf4 *)p = v;
+}
+// same with a uniform base pointer and a 32-bit byte offset per lane (SGPR base + VGPR offset)
+__device__ __forceinline__ void st4o(uint8_t *base, uint32_t off, float a, float b, float c, float e, int nt) {
+    vf4 v = { a, b, c, e };
+    if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else if (nt == 1) __builtin_nontemporal_store(v, (vf4 *)(base + off));
+    else *(vf4 *)(base + off) = v;
+}
+// 4-byte uint8 stores are always plain: `sc1` turned each into its own fabric write (-36 %), non-temporal bought nothing
+__device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int) { *(uint32_t *)(base + off) = v; }
+// Four integer-valued floats -> packed bytes with v_cvt_pk_u8_f32 (one instruction per byte; it saturates to
+// [0, 255], so the uint8 paths need no separate clamp after the truncation; it rounds to nearest, so the
+// truncation itself stays -- measured: without v_trunc the parity tests fail)
+__device__ __forceinline__ uint32_t pack_u8x4(float a, float b, float c, float e) {
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(a, 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(b, 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(c, 2u, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(e, 3u, r);
+}
+__device__ __forceinline__ f2 trunc2(f2 v) { return (f2){ __builtin_truncf(v.x), __builtin_truncf(v.y) }; }
+
+// Merged fp32 outputs (RGB / HSV triples): a thread owns 48 contiguous bytes of an output row, so its three
+// 16-byte stores would interleave with its neighbours' at a 48-byte stride -- every store instruction
+// touches every 128-byte line of the row segment without completing one.  Instead the A active lanes of a
+// "run" (the lanes of one wave that share an output row: min(tx, 64)) swap data through a per-wave LDS slab
+// and store instruction k writes bytes [16 A k, 16 A (k + 1)) of the run's 48 A contiguous bytes.  Only
+// lanes of one wave exchange data and LDS operations of a wave execute in order: no barrier.
+struct MergedRun {
+    uint8_t *lds; // the run's slab
+    int m, a;     // lane index within the run, active lanes of the run (right edge: fewer than the run length)
+};
+template <int OUT, bool VEC> __device__ __forceinline__ MergedRun merged_run(const LaunchDesc &d, int j0) {
+    MergedRun r{ nullptr, 0, 1 };
+    if constexpr (VEC && (OUT == O_F32_MERGED || OUT == O_HSV_F32)) {
+        __shared__ __attribute__((aligned(16))) uint8_t slab[MAX_THREADS * 48];
+        const int len = min(d.tx, 64);
+        r.m = threadIdx.x & (len - 1);
+        r.a = min(len, (d.dst_w - (j0 - PXW * r.m)) / PXW);
+        r.lds = slab + ((int)threadIdx.x - r.m) * 48;
+    }
+    return r;
+}
+
+// One output row of this thread: 4 pixels -> 3 channels, converted and stored.
+template <int OUT, bool VEC>
+__device__ __forceinline__ void color_store_row(const float Yf[PXW], const float t0[2], const float tg[2], const float t2[2],
+                                                const tsvpp_coeffs &k, typename OutT<OUT>::type *out, uint32_t pix, uint32_t plane, int ncol, int nt,
+                                                const MergedRun &run) {
+    using T = typename OutT<OUT>::type;
+    constexpr bool PLANAR = (OUT == O_U8_PLANAR || OUT == O_F32_PLANAR);
+    f2 c0[2], c1[2], c2[2]; // channel values of pixel pairs (0,1) and (2,3)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        f2 y = { Yf[2 * p], Yf[2 * p + 1] };
+        y = y - (f2){ k.y_offset, k.y_offset };
+        y.x = __builtin_fmaxf(0.0f, y.x);
+        y.y = __builtin_fmaxf(0.0f, y.y);
+        y = y * (f2){ k.y_scale, k.y_scale };
+        if constexpr (sizeof(T) == 1) { // the saturating pack below clamps (same arithmetic on the vector and the element-wise path:
+                                        // the row-tail branch then shares every value with the main path instead of recomputing it)
+            c0[p] = trunc2(y + (f2){ t0[p], t0[p] });
+            c1[p] = trunc2(y + (f2){ tg[p], tg[p] });
+            c2[p] = trunc2(y + (f2){ t2[p], t2[p] });
+        } else {
+            c0[p] = trunc_clamp255(y + (f2){ t0[p], t0[p] });
+            c1[p] = trunc_clamp255(y + (f2){ tg[p], tg[p] });
+            c2[p] = trunc_clamp255(y + (f2){ t2[p], t2[p] });
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            c0[p] = norm255(c0[p]);
+            c1[p] = norm255(c1[p]);
+            c2[p] = norm255(c2[p]);
+        }
+        if constexpr (OUT == O_HSV_F32) { // (c0, c1, c2) = normalised (R, G, B) -> merged (H, S, V)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                float h[2], sa[2], v[2];
+                hsv_pixel(c0[p].x, c1[p].x, c2[p].x, h[0], sa[0], v[0]);
+                hsv_pixel(c0[p].y, c1[p].y, c2[p].y, h[1], sa[1], v[1]);
+                c0[p] = (f2){ h[0], h[1] };
+                c1[p] = (f2){ sa[0], sa[1] };
+                c2[p] = (f2){ v[0], v[1] };
+            }
+        }
+        float *o = (float *)out;
+        if constexpr (VEC) {
+            if constexpr (PLANAR) {
+                // uniform plane bases (SGPR pairs) + one 32-bit byte offset per lane
+                const uint32_t boff = pix * 4u;
+                uint8_t *b0 = (uint8_t *)o, *b1 = (uint8_t *)(o + plane), *b2 = (uint8_t *)(o + 2 * (size_t)plane);
+                st4o(b0, boff, c0[0].x, c0[0].y, c0[1].x, c0[1].y, nt);
+                st4o(b1, boff, c1[0].x, c1[0].y, c1[1].x, c1[1].y, nt);
+                st4o(b2, boff, c2[0].x, c2[0].y, c2[1].x, c2[1].y, nt);
+            } else {
+                // merged: the lanes of a run exchange their 48-byte pixel quads through LDS so that each
+                // store instruction of the run writes one contiguous 16 * A byte span (see MergedRun)
+                uint8_t *w = run.lds;
+                *(vf4 *)(w + 48 * run.m) = (vf4){ c0[0].x, c1[0].x, c2[0].x, c0[0].y };
+                *(vf4 *)(w + 48 * run.m + 16) = (vf4){ c1[0].y, c2[0].y, c0[1].x, c1[1].x };
+                *(vf4 *)(w + 48 * run.m + 32) = (vf4){ c2[1].x, c0[1].y, c1[1].y, c2[1].y };
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t q = (pix - 4u * (uint32_t)run.m) * 12u; // first byte of the run in this row
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    const uint32_t off = (uint32_t)(kk * run.a + run.m) * 16u;
+                    const vf4 v = *(const vf4 *)(w + off);
+                    st4o((uint8_t *)o, q + off, v.x, v.y, v.z, v.w, nt);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            const float v0[4] = { c0[0].x, c0[0].y, c0[1].x, c0[1].y }, v1[4] = { c1[0].x, c1[0].y, c1[1].x, c1[1].y },
+                        v2[4] = { c2[0].x, c2[0].y, c2[1].x, c2[1].y };
+            for (int c = 0; c < ncol; c++) {
+                if constexpr (PLANAR) {
+                    o[pix + c] = v0[c];
+                    o[plane + pix + c] = v1[c];
+                    o[2 * plane + pix + c] = v2[c];
+                } else {
+                    o[3 * (pix + c)] = v0[c];
+                    o[3 * (pix + c) + 1] = v1[c];
+                    o[3 * (pix + c) + 2] = v2[c];
+                }
+            }
+        }
+    } else {
+        uint8_t *o = (uint8_t *)out;
+        if constexpr (VEC) {
+            if constexpr (PLANAR) {
+                st1o(o, pix, pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), nt);
+                st1o(o + plane, pix, pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y), nt);
+                st1o(o + 2 * (size_t)plane, pix, pack_u8x4(c2[0].x, c2[0].y, c2[1].x, c2[1].y), nt);
+            } else {
+                st1o(o, 3u * pix, pack_u8x4(c0[0].x, c1[0].x, c2[0].x, c0[0].y), nt);
+                st1o(o, 3u * pix + 4u, pack_u8x4(c1[0].y, c2[0].y, c0[1].x, c1[1].x), nt);
+                st1o(o, 3u * pix + 8u, pack_u8x4(c2[1].x, c0[1].y, c1[1].y, c2[1].y), nt);
+            }
+        } else {
+            const uint32_t p0 = pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), p1 = pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y),
+                           p2 = pack_u8x4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
+            for (int c = 0; c < ncol; c++) {
+                const uint8_t v0 = (uint8_t)(p0 >> (8 * c)), v1 = (uint8_t)(p1 >> (8 * c)), v2 = (uint8_t)(p2 >> (8 * c));
+                if constexpr (PLANAR) {
+                    o[pix + c] = v0;
+                    o[plane + pix + c] = v1;
+                    o[2 * plane + pix + c] = v2;
+                } else {
+                    o[3 * (pix + c)] = v0;
+                    o[3 * (pix + c) + 1] = v1;
+                    o[3 * (pix + c) + 2] = v2;
+                }
+            }
+        }
+    }
+}
+
+// Colour-convert + store a thread tile (2 rows x 4 columns) given its resized samples.
+template <int OUT, bool VEC>
+__device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const float Uf[2], const float Vf[2], const LaunchDesc &d,
+                                                 typename OutT<OUT>::type *out, int i0, int j0, int ncol) {
+    if constexpr (OUT == O_NV12_U8 || OUT == O_NV12_F32 || OUT == O_Y800_U8 || OUT == O_Y800_F32) {
+        // no colour conversion: the resized samples themselves (fp32: / 255), Y plane then UV plane
+        using T = typename OutT<OUT>::type;
+        constexpr bool CHROMA = (OUT == O_NV12_U8 || OUT == O_NV12_F32);
+        const int nt = d.nt_stores;
+        const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+        const uint32_t cpix = plane + (uint32_t)(i0 >> 1) * (uint32_t)d.dst_w + (uint32_t)j0;
+        if constexpr (sizeof(T) == 1) {
+            uint8_t *o = (uint8_t *)out;
+            auto pk = [](float a, float b, float c, float e) { return pack_u8x4(a, b, c, e); };
+#pragma unroll
+            for (int r = 0; r < PXH; r++) {
+                const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+                if constexpr (VEC) st1o(o, pix, pk(Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3]), nt);
+                else
+                    for (int c = 0; c < ncol; c++) o[pix + c] = (uint8_t)Yf[r][c];
+            }
+            if constexpr (CHROMA) {
+                if constexpr (VEC) st1o(o, cpix, pk(Uf[0], Vf[0], Uf[1], Vf[1]), nt);
+                else {
+                    o[cpix] = (uint8_t)Uf[0];
+                    o[cpix + 1] = (uint8_t)Vf[0];
+                    if (ncol > 2) {
+                        o[cpix + 2] = (uint8_t)Uf[1];
+                        o[cpix + 3] = (uint8_t)Vf[1];
+                    }
+                }
+            }
+        } else {
+            float *o = (float *)out;
+#pragma unroll
+            for (int r = 0; r < PXH; r++) {
+                const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+                const f2 a = norm255((f2){ Yf[r][0], Yf[r][1] }), b = norm255((f2){ Yf[r][2], Yf[r][3] });
+                if constexpr (VEC) st4o((uint8_t *)o, pix * 4u, a.x, a.y, b.x, b.y, nt);
+                else {
+                    const float v[4] = { a.x, a.y, b.x, b.y };
+                    for (int c = 0; c < ncol; c++) o[pix + c] = v[c];
+                }
+            }
+            if constexpr (CHROMA) {
+                const f2 a = norm255((f2){ Uf[0], Vf[0] }), b = norm255((f2){ Uf[1], Vf[1] });
+                if constexpr (VEC) st4o((uint8_t *)o, cpix * 4u, a.x, a.y, b.x, b.y, nt);
+                else {
+                    o[cpix] = a.x;
+                    o[cpix + 1] = a.y;
+                    if (ncol > 2) {
+                        o[cpix + 2] = b.x;
+                        o[cpix + 3] = b.y;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    float t0[2], tg[2], t2[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+    // 32-bit element offsets from the frame's (uniform) base pointer: the stores use the
+    // SGPR-base + VGPR-offset addressing mode instead of per-lane 64-bit pointer arithmetic
+    // (host side guarantees 3 * W * H * sizeof(T) < 4 GiB)
+    const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+    const MergedRun run = merged_run<OUT, VEC>(d, j0);
+#pragma unroll
+    for (int r = 0; r < PXH; r++)
+        color_store_row<OUT, VEC>(Yf[r], t0, tg, t2, d.k, out, (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0, plane, ncol, d.nt_stores, run);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Work decomposition shared by all kernels.
+struct TileId {
+    int frame, tx, ty;
+    bool valid;
+};
+// tile_order 0 (default): workgroup id -> tile such that (a) the workgroups resident at any moment
+// cover a contiguous run of tile rows of one or two frames (HBM write locality: measured +2..5 %
+// over giving each XCD its own frames) and (b) a whole tile ROW lands on one XCD (id % 8), so the
+// 128-byte lines that horizontally adjacent tiles share are fetched into one L2 once.
+// tile_order 1: plain raster.  tile_order 2: XCD-contiguous runs of (frame, tile).
+__device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
+    TileId t;
+    const int tiles = d.tiles_x * d.tiles_y;
+    if (d.tile_order == 0) {
+        const int x = blockIdx.x % NUM_XCD, q = blockIdx.x / NUM_XCD;
+        const int group = q / d.tiles_x;
+        t.tx = q - group * d.tiles_x;
+        const int row = group * NUM_XCD + x; // global tile row = frame * tiles_y + ty
+        t.frame = row / d.tiles_y;
+        t.ty = row - t.frame * d.tiles_y;
+        t.valid = row < d.tiles_y * d.n_frames;
+        return t;
+    }
+    const int total = tiles * d.n_frames;
+    const int logical = d.tile_order == 1 ? (int)blockIdx.x : (int)((blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD);
+    t.valid = logical < total;
+    t.frame = logical / tiles;
+    const int rem = logical - t.frame * tiles;
+    t.ty = rem / d.tiles_x;
+    t.tx = rem - t.ty * d.tiles_x;
+    return t;
+}
+
+// Generic thread tile: samplers (any mode, any reader) -> colour back end.
+template <int MODE, int OUT, bool VEC, class S>
+__device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc &d, typename OutT<OUT>::type *out, int i0, int j0) {
+    // VEC: the thread tile has its four columns.  Element-wise flavour: dst_w is even, so 2 or 4 columns (2 in the last
+    // thread tile of a row when dst_w = 4 k + 2); a column that does not exist is sampled at the row's last one
+    // instead -- in bounds, branch-free -- and never stored.
+    const int ncol = VEC ? PXW : min(PXW, d.dst_w - j0);
+    const int ci = i0 >> 1, cj0 = j0 >> 1, jmax = d.dst_w - 1, cjmax = (d.dst_w >> 1) - 1;
+    float Uf[2], Vf[2], Yf[PXH][PXW];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        int U = 128, V = 128;
+        if constexpr (!kLumaOnly<OUT>) sample_chroma<MODE>(s, d, ci, VEC ? cj0 + c : min(cj0 + c, cjmax), U, V);
+        Uf[c] = (float)U;
+        Vf[c] = (float)V;
+    }
+#pragma unroll
+    for (int r = 0; r < PXH; r++)
+#pragma unroll
+        for (int c = 0; c < PXW; c++) Yf[r][c] = (float)sample_luma<MODE>(s, d, i0 + r, VEC ? j0 + c : min(j0 + c, jmax));
+    color_store_tile<OUT, VEC>(Yf, Uf, Vf, d, out, i0, j0, ncol);
+}
+
+// dst_w = 4 k + 2 (854, 1366, ...): the last thread tile of every row has only two columns.  The vector-store kernels
+// skip it (is_row_tail) and launch_fused covers those two columns with a second, tiny launch of the element-wise
+// gather kernel (one thread tile per row pair; LaunchDesc::col0).  Both cheaper alternatives were measured and
+// rejected: a fallback at store time keeps every sample live across its branch (gather / direct / colour-only
+// kernels 4-10 % slower although it is almost never taken), and an early exit into an inlined generic path drags that
+// path's registers into every kernel (C4's point kernel: 30 -> 110 VGPRs, 25 % slower).
+__device__ __forceinline__ bool is_row_tail(const LaunchDesc &d, int j0) { return d.dst_w - j0 < PXW; }
+
+// ----------------------------------------------------------------------------------------------
+// Source footprint of a run of outputs [o0, o1] along one axis: first and last source sample any
+// of them taps, from the SAME coordinate functions the samplers use (they are monotonic in o).
+template <int MODE>
+__device__ __forceinline__ void axis_span(int o0, int o1, float ratio, int limit, int taps, int &lo, int &hi) {
+    if constexpr (MODE == M_NONE) {
+        lo = o0;
+        hi = o1;
+    } else if constexpr (MODE == M_NEAREST) {
+        lo = (int)(ratio * (float)o0);
+        hi = (int)(ratio * (float)o1);
+    } else if constexpr (MODE == M_AREA_DOWN) {
+        lo = (int)(ratio * (float)o0);
+        hi = (int)(ratio * (float)o1) + taps - 1;
+    } else if constexpr (MODE == M_BILINEAR) {
+        float w;
+        bilinear_axis(o0, ratio, limit, lo, w);
+        bilinear_axis(o1, ratio, limit, hi, w);
+        hi += 1;
+    } else if constexpr (MODE == M_AREA_UP) {
+        float w;
+        areaup_axis(o0, ratio, lo, w);
+        areaup_axis(o1, ratio, hi, w);
+        hi += 1;
+    } else { // M_BICUBIC
+        double w;
+        bicubic_axis(o0, ratio, limit, lo, w);
+        bicubic_axis(o1, ratio, limit, hi, w);
+        lo -= 1;
+        hi += 2;
+    }
+}
+
+// Footprint of one workgroup tile in both planes (luma columns/rows; chroma PAIR columns/rows).
+struct Footprint {
+    int j_first, i_first, j_last, i_last;
+    int xlo, xhi, ylo, yhi, cxlo, cxhi, cylo, cyhi;
+};
+template <int MODE>
+__device__ __forceinline__ Footprint tile_footprint(const LaunchDesc &d, const TileId &id) {
+    Footprint f;
+    f.j_first = id.tx * d.tx * PXW;
+    f.i_first = id.ty * d.ty * PXH * d.rpt;
+    f.j_last = min(f.j_first + d.tx * PXW, d.dst_w) - 1;
+    f.i_last = min(f.i_first + d.ty * PXH * d.rpt, d.dst_h) - 1;
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+    axis_span<MODE>(f.j_first, f.j_last, d.xr, d.src_w, d.rx, f.xlo, f.xhi);
+    axis_span<MODE>(f.i_first, f.i_last, d.yr, d.src_h, d.ry, f.ylo, f.yhi);
+    f.xlo = max(f.xlo, 0);
+    f.ylo = max(f.ylo, 0);
+    f.xhi = min(f.xhi, d.src_w - 1);
+    f.yhi = min(f.yhi, d.src_h - 1);
+    // chroma: the same formulas on the chroma grid (dst_w, dst_h are even)
+    axis_span<MODE>(f.j_first >> 1, f.j_last >> 1, d.xr, d.src_w, d.rx, f.cxlo, f.cxhi);
+    axis_span<MODE>(f.i_first >> 1, f.i_last >> 1, d.yr, d.src_h, d.ry, f.cylo, f.cyhi);
+    f.cxlo = max(f.cxlo, 0);
+    f.cylo = max(f.cylo, 0);
+    f.cxhi = min(f.cxhi, cw - 1);
+    f.cyhi = min(f.cyhi, chh - 1);
+    return f;
+}
+
+// Describe / stage rows [row_lo, row_lo + nrows) x byte columns [col_lo, col_lo + span) of one
+// plane into LDS with 16-byte aligned global loads.  A 16-byte aligned chunk that overlaps at
+// least one valid byte lies in the same page as that byte, so the over-read at the ends of a row
+// never faults.  2^slot_shift lanes serve one row (lanes >= cpr idle): no integer division.
+__device__ __forceinline__ LdsPlane describe_plane(uint8_t *lds, const uint8_t *plane, int pitch, int row_lo, int col_lo, int cpr,
+                                                   const uint8_t *&a0) {
+    a0 = plane + (size_t)row_lo * (size_t)pitch + (size_t)col_lo;
+    LdsPlane lp;
+    lp.base = lds;
+    lp.x0 = col_lo;
+    lp.y0 = row_lo;
+    lp.lp = 16 * cpr;
+    lp.m0 = (int)((uintptr_t)a0 & 15);
+    lp.pm = pitch & 15;
+    return lp;
+}
+// All loads of a round -- both planes -- are issued before the first LDS write (K rows per lane in
+// flight): with a plain load->write loop the compiler has to wait for each chunk before issuing
+// the next and the workgroup pays the HBM latency once per row group instead of once.  The loads
+// are branch-free (clamped addresses; only the LDS write is predicated).
+struct StageLane {
+    int ch, r0, rstep;
+};
+__device__ __forceinline__ StageLane stage_lane(int slot_shift, int nthreads) {
+    return StageLane{ (int)(threadIdx.x & ((1 << slot_shift) - 1)), (int)(threadIdx.x >> slot_shift), nthreads >> slot_shift };
+}
+template <int K>
+__device__ __forceinline__ void stage_issue(const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span, int cpr, const StageLane &ln,
+                                            int base, uint4 v[K], bool ok[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = base + k * ln.rstep + ln.r0;
+        const int rc = min(r, nrows - 1);
+        const int mis = (lp.m0 + rc * lp.pm) & 15;
+        const int chmax = (mis + span - 1) >> 4;
+        ok[k] = (ln.ch < cpr) && (r < nrows) && (ln.ch <= chmax);
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (base + k * ln.rstep < nrows) // uniform
+            v[k] = *(const uint4 *)(a0 + (size_t)rc * (size_t)pitch - mis + 16 * min(ln.ch, chmax));
+    }
+}
+template <int K>
+__device__ __forceinline__ void stage_commit(uint8_t *lds, const LdsPlane &lp, const StageLane &ln, int base, const uint4 v[K], const bool ok[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = base + k * ln.rstep + ln.r0;
+        if (ok[k]) *(uint4 *)(lds + r * lp.lp + 16 * ln.ch) = v[k];
+    }
+}
+template <int KY, int KUV>
+__device__ __forceinline__ void stage_planes(const LaunchDesc &d, uint8_t *lds_y, const uint8_t *ay, const LdsPlane &py, int ny, int span_y,
+                                             uint8_t *lds_uv, const uint8_t *auv, const LdsPlane &puv, int nuv, int span_uv, int nthreads) {
+    const StageLane ly = stage_lane(d.lds_slot_y, nthreads), luv = stage_lane(d.lds_slot_uv, nthreads);
+    for (int it = 0;; it++) {
+        const int by = it * KY * ly.rstep, buv = it * KUV * luv.rstep;
+        if (by >= ny && buv >= nuv) break;
+        uint4 vy[KY], vuv[KUV];
+        bool oky[KY], okuv[KUV];
+        stage_issue<KY>(ay, py, d.pitch_y, ny, span_y, d.lds_cpr_y, ly, by, vy, oky);
+        stage_issue<KUV>(auv, puv, d.pitch_uv, nuv, span_uv, d.lds_cpr_uv, luv, buv, vuv, okuv);
+        stage_commit<KY>(lds_y, py, ly, by, vy, oky);
+        stage_commit<KUV>(lds_uv, puv, luv, buv, vuv, okuv);
+    }
+}
+
+// LDS-DMA variant (global_load_lds_dwordx4): the chunks go straight from HBM into LDS, no VGPR
+// round trip and no ds_write.  Lane l of a wave instruction lands in LDS slot (wave base + 16 l),
+// so it needs the row pitch to be a power-of-two number of chunks (16 << slot): then the slot of
+// (row r, chunk ch) IS 16 * thread-linear index.  Idle lanes (ch >= cpr, rows past the footprint)
+// fetch a clamped valid chunk into their padding slot.  Rows must be allocated up to a multiple
+// of the rows per round.  The caller waits (vmcnt(0)) and barriers.
+__device__ __forceinline__ void stage_plane_dma(uint8_t *lds, const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span,
+                                                int slot_shift, int nthreads) {
+    const int ch = threadIdx.x & ((1 << slot_shift) - 1);
+    const int r0 = threadIdx.x >> slot_shift;
+    const int rstep = nthreads >> slot_shift;
+    const int wave_row0 = (int)((threadIdx.x & ~63u) >> slot_shift); // first row this wave serves in round 0
+    for (int base = 0; base + wave_row0 < nrows; base += rstep) {     // wave-uniform trip count
+        const int rc = min(base + r0, nrows - 1);
+        const int mis = (lp.m0 + rc * lp.pm) & 15;
+        const int chmax = (mis + span - 1) >> 4;
+        const uint8_t *src = a0 + (size_t)rc * (size_t)pitch - mis + 16 * min(ch, chmax);
+        uint8_t *dst = lds + ((base << slot_shift) + (int)(threadIdx.x & ~63u)) * 16; // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+
+} // namespace tsvpp

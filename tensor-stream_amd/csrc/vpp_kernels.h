@@ -72,6 +72,9 @@ struct LaunchDesc {
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
+    int bic_dyadic;         // host: every BICUBIC weight of this request is a multiple of 1/16 (integer kernel eligible)
+    int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
+    int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
     int area_cols_pref, area_cols; // column-per-lane float AREA kernel allowed (TSVPP_AREA_COLS) / chosen by launch_fused
     int col0;               // first output column of this launch (0; dst_w & ~3 in the row-tail launch of widths 4 k + 2)
@@ -99,6 +102,10 @@ struct LaunchInfo {
 // Returns hipError_t.
 // `info` != nullptr: a dry run -- the selection is recorded there and nothing is launched.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info = nullptr);
+
+// Integer BICUBIC kernel for dyadic weights (vpp_bicubic_int.hip): LDS bytes it needs beyond the staged planes, launch.
+size_t bicubic_int_table_bytes(int tw, int th, int rows_y, int rows_uv, int hcs_y, int hcs_uv);
+hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);
 // t.y / t.uv are the (resized or cropped) NV12 planes, t.out the outputs.

@@ -15,13 +15,19 @@ def plan(src, dst=(0, 0), rt=N, fourcc=BGR24, planes=0, norm=True, crop=(0, 0, 0
     return ts.describe(fp, src[0], src[1], pitch=pitch, **kw)
 
 
-def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
+def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
+    """Round 2: the fp32 2x2-tap kernel sits at the HBM floor of its tile pattern and 256 x 8 tiles have the lowest one
+    (tools/membench2.hip; profiles/r02_shape_sweep.txt): 64 x 4 thread tiles, one row pair per thread."""
     p = plan((1920, 1080), (1280, 720), B, pitch=2048)
     assert p["mode"] == "bilinear" and p["out"] == "f32_planar"
-    assert p["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>" and (p["shape"], p["rpt"], p["dma"]) == ("32x8", 2, 1)
-    assert p["tiles"] == "10x23" and p["frames"] == 64 and p["lds"] <= 40 * 1024
+    assert p["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>" and (p["shape"], p["rpt"], p["dma"]) == ("64x4", 1, 1)
+    assert p["tiles"] == "5x90" and p["frames"] == 64 and p["lds"] <= 40 * 1024
     # whole tile rows per XCD: rows padded to a multiple of 8
-    assert p["grid"] == (23 * 64 + 7) // 8 * 8 * 10
+    assert p["grid"] == (90 * 64 + 7) // 8 * 8 * 5
+    # widths that do not fill 256-wide tiles stay on 128; uint8 outputs (VALU-bound) keep the tall thread tiles
+    assert plan((3840, 2160), (1920, 1080), B)["shape"] == "32x8"
+    p = plan((1920, 1080), (1280, 720), B, norm=False)
+    assert (p["shape"], p["rpt"]) == ("32x8", 2)
 
 
 @pytest.mark.parametrize("src,dst,rt,kernel", [
@@ -40,7 +46,11 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_with_tall_thread_tiles():
     ((1920, 1080), (224, 224), A, "vpp_area_direct_float_kernel<3"),     # 8.57 x 4.82
     ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2"),             # 6.4 x 3.6: one output column per lane
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
-    ((1920, 1080), (1280, 720), C, "vpp_bicubic_sep_kernel"),
+    ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
+    ((3840, 2160), (1920, 1080), C, "vpp_bicubic_int_kernel"),          # 2: halves
+    ((960, 540), (1920, 1080), C, "vpp_bicubic_int_kernel"),            # 0.5
+    ((1280, 720), (1920, 1080), C, "vpp_bicubic_sep_kernel"),           # 2/3: not dyadic -> float kernel
+    ((1080, 608), (480, 360), C, "vpp_bicubic_sep_kernel"),
     ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
     ((1920, 1080), (224, 224), C, "vpp_fused_gather_kernel"),
 ])
@@ -55,11 +65,14 @@ def test_c3_crop_folds_into_pointers_and_the_sparse_bilinear_gathers():
 
 
 def test_small_outputs_keep_two_row_thread_tiles():
-    # 48 * num_cus workgroups are needed before the 4-row thread tile pays in the 2x2-tap kernel (16 in the others)
-    assert plan((1920, 1080), (1280, 720), B, n_frames=8)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
-    assert plan((1920, 1080), (1280, 720), B, n_frames=64)["rpt"] == 2   # 14720 >= 12288
-    assert plan((1920, 1080), (960, 540), B, n_frames=64)["rpt"] == 1    # 8704: measured 7 % faster with two-row tiles
-    assert plan((3840, 2160), (1920, 1080), B, n_frames=64)["rpt"] == 2
+    # fp32 2x2-tap kernel: always one row pair (the HBM write pattern prefers short tiles); the VALU-bound flavours take
+    # the 4-row thread tile once the launch has 48 * num_cus workgroups (16 in the other kernels)
+    for n in (8, 64):
+        assert plan((1920, 1080), (1280, 720), B, n_frames=n)["rpt"] == 1
+    assert plan((3840, 2160), (1920, 1080), B, n_frames=64)["rpt"] == 1
+    assert plan((1920, 1080), (1280, 720), B, n_frames=8, norm=False)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
+    assert plan((1920, 1080), (1280, 720), B, n_frames=64, norm=False)["rpt"] == 2   # 14720 >= 12288
+    assert plan((1920, 1080), (960, 540), B, n_frames=64, norm=False)["rpt"] == 1    # 8704
     # dyadic AREA: most resident workgroups first (1080p -> 960x540: the compact two-row layout, 19.7 KiB, 8 per CU)
     p = plan((1920, 1080), (960, 540), A, n_frames=64)
     assert (p["rpt"], p["dma"]) == (1, 0) and p["lds"] < 20 * 1024
