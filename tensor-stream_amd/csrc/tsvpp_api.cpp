@@ -690,6 +690,9 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
             t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
         }
         d.n_frames = cnt;
+#ifdef TSVPP_DEBUG_LDS
+        if (const char *dp = std::getenv("TSVPP_DEBUG_PTR")) t.out[TSVPP_MAX_BATCH - 1] = (void *)std::strtoull(dp, nullptr, 0);
+#endif
         // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel); scratch frames are
         // 256-byte aligned.
         bool vec = true;

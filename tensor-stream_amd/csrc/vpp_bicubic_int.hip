@@ -7,7 +7,7 @@
 // sum is exact in fp64, and round() sees the exact value -- so the whole evaluation can be done in INTEGERS, bit for bit:
 //     S = sum_t C_t p_t  with C_t = 16384 c_t (|C_t| <= 18811, fits int16),   value = clamp((S + 8192) >> 14, 0, 255)
 // (S < 0 rounds to <= 0 and clamps to 0 either way).  Two v_dot2_i32_i16 per 4-tap sum, the rounding bias in the
-// accumulator input, one arithmetic shift, one v_med3_i32 -- against ~14 packed/scalar float operations, a tie test and an
+// accumulator input, and v_ashr_pk_u8_i32 shifts, clamps and packs two values at once -- against ~14 packed/scalar float operations, a tie test and an
 // fp64 fallback per sum in the general kernel (vpp_bicubic_sep_kernel, which stays the path for every other ratio).
 //
 // Structure (separable, like the general kernel): the footprint is staged in LDS (LDS-DMA or registers); phase 1
@@ -47,23 +47,36 @@ __device__ __forceinline__ void bicubic_int_axis(int idx, float ratio, int clamp
     c23 = (wg[2] & 0xffff) | (wg[3] << 16);
 }
 
-// clamp(round(S / 16384), 0, 255) of the 4-tap sum over the bytes of q (tap t in byte t)
-__device__ __forceinline__ int cubic_int4(uint32_t q, int c01, int c23) {
+// S + 8192 of the 4-tap sum over the bytes of q (tap t in byte t); the value is clamp(that >> 14, 0, 255)
+__device__ __forceinline__ int cubic_sum4(uint32_t q, int c01, int c23) {
     const uint32_t p01 = __builtin_amdgcn_perm(0u, q, 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, q, 0x0c030c02u);
     int s = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p01), __builtin_bit_cast(s16x2, c01), 8192, false);
-    s = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p23), __builtin_bit_cast(s16x2, c23), s, false);
-    return max(min(s >> 14, 255), 0);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p23), __builtin_bit_cast(s16x2, c23), s, false);
 }
 // the same for interleaved (U, V) bytes: q0 = U0 V0 U1 V1, q1 = U2 V2 U3 V3
-__device__ __forceinline__ void cubic_int4_uv(uint32_t q0, uint32_t q1, int c01, int c23, int &u, int &v) {
+__device__ __forceinline__ void cubic_sum4_uv(uint32_t q0, uint32_t q1, int c01, int c23, int &su, int &sv) {
     const uint32_t u01 = __builtin_amdgcn_perm(0u, q0, 0x0c020c00u), u23 = __builtin_amdgcn_perm(0u, q1, 0x0c020c00u);
     const uint32_t v01 = __builtin_amdgcn_perm(0u, q0, 0x0c030c01u), v23 = __builtin_amdgcn_perm(0u, q1, 0x0c030c01u);
-    int su = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, u01), __builtin_bit_cast(s16x2, c01), 8192, false);
+    su = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, u01), __builtin_bit_cast(s16x2, c01), 8192, false);
     su = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, u23), __builtin_bit_cast(s16x2, c23), su, false);
-    int sv = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, v01), __builtin_bit_cast(s16x2, c01), 8192, false);
+    sv = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, v01), __builtin_bit_cast(s16x2, c01), 8192, false);
     sv = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, v23), __builtin_bit_cast(s16x2, c23), sv, false);
-    u = max(min(su >> 14, 255), 0);
-    v = max(min(sv >> 14, 255), 0);
+}
+// Four biased sums -> four bytes clamp(s >> 14, 0, 255), s0 in byte 0.  gfx950's V_ASHR_PK_U8_I32 shifts, saturates to
+// [0, 255] and packs two values into the LOW 16 bits of its destination and leaves the upper 16 bits as they were
+// (measured: tools/dbg_prims2 -- and the compiler of ROCm 7.2, which selects this instruction for the C expression
+// max(min(s >> 14, 255), 0) | ... << 8, assumes they are zeroed: the first version of this kernel, written that way,
+// OR-ed stale register contents into every third byte).  Written out as inline assembly, the preserved upper half is used
+// on purpose: pair (s2, s3) is packed first and shifted up, pair (s0, s1) then lands below it.  Three instructions for
+// four values instead of four shifts, four v_med3 and three v_lshl_or.
+__device__ __forceinline__ uint32_t round_clamp_pack4(int s0, int s1, int s2, int s3) {
+    uint32_t hi;
+    // s_nop 2: a VALU read of a v_dot2c result needs three wait states; the compiler inserts them in its own code but does
+    // not look into inline assembly (the sums usually come straight out of a v_dot2c_i32_i16)
+    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 14" : "=v"(hi) : "v"(s2), "v"(s3)); // upper half: don't care, shifted out below
+    uint32_t r = hi << 16;
+    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 14" : "+v"(r) : "v"(s0), "v"(s1));
+    return r;
 }
 
 // physical column of tile column c in the H planes: thread lx's k-th column (c = 4 lx + k) lives at k * tx + lx, so the
@@ -151,15 +164,14 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_int_kernel(const Laun
             const ICol e = xtab[c];
             const int4 rb = *(const int4 *)(rby + 4 * g);
             const int rbs[4] = { rb.x, rb.y, rb.z, rb.w };
-            uint32_t pack = 0;
+            int sm[4];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int A = rbs[rr] + e.off;
                 const uint32_t *p = (const uint32_t *)(lds_y + (A & ~3));
-                const uint32_t q = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)A & 3u);
-                pack |= (uint32_t)cubic_int4(q, e.c01, e.c23) << (8 * rr);
+                sm[rr] = cubic_sum4(__builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)A & 3u), e.c01, e.c23);
             }
-            *(uint32_t *)(hy + hcol(c, d.tx) * d.hcs_y + 4 * g) = pack;
+            *(uint32_t *)(hy + hcol(c, d.tx) * d.hcs_y + 4 * g) = round_clamp_pack4(sm[0], sm[1], sm[2], sm[3]);
         }
         const int ngc = (nuv + 3) >> 2;
         const int cw_shift = tw_shift - 1;
@@ -169,23 +181,28 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_int_kernel(const Laun
             const ICol e = cxtab[cp];
             const int4 rb = *(const int4 *)(rbuv + 4 * g);
             const int rbs[4] = { rb.x, rb.y, rb.z, rb.w };
-            uint32_t pu = 0, pv = 0;
+            int su[4], sv[4];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int A = rbs[rr] + e.off;
                 const uint32_t *p = (const uint32_t *)(lds_uv + (A & ~3));
                 const uint32_t sh = (uint32_t)A & 3u;
                 const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-                int u, v;
-                cubic_int4_uv(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh), e.c01, e.c23, u, v);
-                pu |= (uint32_t)u << (8 * rr);
-                pv |= (uint32_t)v << (8 * rr);
+                cubic_sum4_uv(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh), e.c01, e.c23, su[rr], sv[rr]);
             }
+            const uint32_t pu = round_clamp_pack4(su[0], su[1], su[2], su[3]), pv = round_clamp_pack4(sv[0], sv[1], sv[2], sv[3]);
             *(uint32_t *)(huv + hcol(2 * cp, d.tx) * d.hcs_uv + 4 * g) = pu;
             *(uint32_t *)(huv + hcol(2 * cp + 1, d.tx) * d.hcs_uv + 4 * g) = pv;
         }
     }
     __syncthreads();
+#ifdef TSVPP_DEBUG_LDS // debugging aid (make DEBUG_LDS=1): workgroup 0 copies its whole LDS image to the buffer smuggled in t.out[63]
+    if (blockIdx.x == 0 && t.out[TSVPP_MAX_BATCH - 1] != nullptr) {
+        uint32_t *dst = (uint32_t *)t.out[TSVPP_MAX_BATCH - 1];
+        const int nd = (int)(((uint8_t *)(rbuv + nrb_uv) - lds_raw + 3) / 4);
+        for (int i = threadIdx.x; i < nd; i += nthreads) dst[i] = ((const uint32_t *)lds_raw)[i];
+    }
+#endif
 
     // phase 2: vertical sums of this thread's 4 columns, two output rows (one chroma row) per step
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
@@ -204,21 +221,29 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_int_kernel(const Laun
         float cv[PXW] = { 128.0f, 128.0f, 128.0f, 128.0f }, Yf[PXH][PXW];
         if constexpr (!kLumaOnly<OUT>) {
             const IRow e = cytab[lyr];
+            int sm[PXW];
 #pragma unroll
             for (int k = 0; k < PXW; k++) {
                 const uint32_t *p = (const uint32_t *)(colC[k] + e.al);
-                cv[k] = (float)cubic_int4(__builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)e.sh), e.c01, e.c23);
+                sm[k] = cubic_sum4(__builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)e.sh), e.c01, e.c23);
             }
+            const uint32_t w = round_clamp_pack4(sm[0], sm[1], sm[2], sm[3]);
+#pragma unroll
+            for (int k = 0; k < PXW; k++) cv[k] = (float)((w >> (8 * k)) & 255u);
         }
         const float Uf[2] = { cv[0], cv[2] }, Vf[2] = { cv[1], cv[3] };
 #pragma unroll
         for (int r = 0; r < PXH; r++) {
             const IRow e = ytab[lyr * PXH + r];
+            int sm[PXW];
 #pragma unroll
             for (int k = 0; k < PXW; k++) {
                 const uint32_t *p = (const uint32_t *)(colY[k] + e.al);
-                Yf[r][k] = (float)cubic_int4(__builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)e.sh), e.c01, e.c23);
+                sm[k] = cubic_sum4(__builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)e.sh), e.c01, e.c23);
             }
+            const uint32_t w = round_clamp_pack4(sm[0], sm[1], sm[2], sm[3]);
+#pragma unroll
+            for (int k = 0; k < PXW; k++) Yf[r][k] = (float)((w >> (8 * k)) & 255u);
         }
         color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
     }
