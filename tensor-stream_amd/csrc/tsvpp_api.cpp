@@ -181,6 +181,7 @@ struct tsvpp_ctx {
     float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
+    int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
     int area_cols = 1;              // TSVPP_AREA_COLS
@@ -284,6 +285,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
@@ -318,6 +320,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_direct_fmin = ctx->area_direct_fmin;
     d.bicubic_sep = ctx->bicubic_sep;
     d.bicubic_int_pref = ctx->bicubic_int;
+    d.area_box_pref = ctx->area_box;
     d.bic_dyadic = pl.bic_dyadic;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
@@ -644,6 +647,8 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         if (tx.qdev && ty.qdev && dyadic_usable(pl.xr, pl.yr, tx.shift, ty.shift)) {
             d.qx = tx.qdev;
             d.qy = ty.qdev;
+            d.box_rx = (tx.rows == 1 && tx.shift == 0 && tx.uniform_sum == tx.taps) ? tx.taps : 0; // one row of all ones
+            d.box_ry = (ty.rows == 1 && ty.shift == 0 && ty.uniform_sum == ty.taps) ? ty.taps : 0;
             // one divisor for the whole frame -> exact integer division by a constant in the kernel
             if (tx.uniform_sum > 0 && ty.uniform_sum > 0 && (long)tx.uniform_sum * ty.uniform_sum < 4096)
                 d.area_rcp = 1.0f / (float)(tx.uniform_sum * ty.uniform_sum);
@@ -789,6 +794,8 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
         d.patx = d.paty = d.patx4 = d.paty4 = dummy_f;
         if (dyadic[0] && dyadic[1] && dyadic_usable(pl.xr, pl.yr, shift[0], shift[1])) {
             d.qx = d.qy = &dummy_q;
+            d.box_rx = (d.nx == 1 && shift[0] == 0 && uniform[0] == d.rx) ? d.rx : 0;
+            d.box_ry = (d.ny == 1 && shift[1] == 0 && uniform[1] == d.ry) ? d.ry : 0;
             if (uniform[0] > 0 && uniform[1] > 0 && (long)uniform[0] * uniform[1] < 4096) d.area_rcp = 1.0f / (float)(uniform[0] * uniform[1]);
         }
     }

@@ -840,6 +840,13 @@ __device__ __forceinline__ void stage_plane_dma(uint8_t *lds, const uint8_t *a0,
     }
 }
 
+// Integer box sum / divisor, truncated (dyadic AREA kernels; the derivation is at vpp_area_dyadic_kernel): with one
+// divisor S for the whole frame (rcp = 1 / S, S < 4096) the quotient is floor((SUM + 0.5) * rcp), else one IEEE division.
+__device__ __forceinline__ float area_quot(uint32_t sum, int sx, int sy, float rcp) {
+    if (rcp != 0.0f) return __builtin_truncf(((float)sum + 0.5f) * rcp);
+    return __builtin_truncf((float)sum / (float)(sx * sy));
+}
+
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
 } // namespace tsvpp

@@ -72,6 +72,8 @@ struct LaunchDesc {
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
+    int box_rx, box_ry;     // host: the AREA weight table of that axis is one row of all ones (integer ratio) -> its tap count, else 0
+    int area_box_pref, area_box; // contiguous-run box kernel allowed (TSVPP_AREA_BOX) / chosen by launch_fused
     int bic_dyadic;         // host: every BICUBIC weight of this request is a multiple of 1/16 (integer kernel eligible)
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
@@ -106,6 +108,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, c
 // Integer BICUBIC kernel for dyadic weights (vpp_bicubic_int.hip): LDS bytes it needs beyond the staged planes, launch.
 size_t bicubic_int_table_bytes(int tw, int th, int rows_y, int rows_uv, int hcs_y, int hcs_uv);
 hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
+
+// AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
+hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);
 // t.y / t.uv are the (resized or cropped) NV12 planes, t.out the outputs.

@@ -887,10 +887,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
 // from one, far more than the division's rounding error).  With one divisor for the whole frame
 // (rcp = 1/S, S < 4096) the quotient is floor((SUM + 0.5) * rcp): the half keeps exact multiples
 // above their integer, and the product's error (< 255 * 2^-22) cannot reach the next one.
-__device__ __forceinline__ float area_quot(uint32_t sum, int sx, int sy, float rcp) {
-    if (rcp != 0.0f) return __builtin_truncf(((float)sum + 0.5f) * rcp);
-    return __builtin_truncf((float)sum / (float)(sx * sy));
-}
+// (area_quot itself lives in vpp_device.h: the box kernel of vpp_area_box.hip shares it)
 struct AXEntry { int off, sum; uint32_t w0, w1; };                // luma column: LDS offset, sum(wx), packed weights
 struct ACEntry { int off, sum; uint32_t wu[4]; int pad0, pad1; }; // chroma pair column: weights on even bytes
 struct AYEntry { int row, sum; uint32_t w0, w1; };                // output row: first staged row, sum(wy), packed weights
@@ -1620,6 +1617,8 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
         }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
+            if (vec && d.area_direct == 1 && d.area_box && !d.force_gather) // integer ratio: contiguous dword runs
+                return launch_area_box((OutKind)OUT, d, t, stream, info);
             if (vec && d.area_direct == 1 && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
                 if (d.rx <= 4) TSVPP_LAUNCH("vpp_area_direct_kernel<1, OUT>", (vpp_area_direct_kernel<1, OUT>), grid, block, 0);
                 else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
@@ -1742,6 +1741,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.area_direct = 2; // float weights
     else
         d.area_direct = 0;
+    // integer horizontal ratio (one all-ones weight row), 4-byte aligned planes and pitches: the box kernel's contiguous runs
+    d.area_box = (d.area_direct == 1 && d.area_box_pref && d.box_rx >= 4 && d.box_rx <= 8 && d.box_rx == d.rx && d.in_aligned4 && d.ry <= 8) ? 1 : 0;
     // measured (tools/ab: TSVPP_AREA_COLS=0/1/2): the column-per-lane kernel wins at 5-8 horizontal taps (1080p -> 300^2
     // +17 %, -> 416^2 +34 %, 4K -> 608x342 +11 %), is even at 2-4 and loses at 9+ (1080p -> 224^2 -6 %: 102 VGPRs and
     // half-empty 64 x 32 tiles); 2 = always

@@ -35,8 +35,11 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (1280, 720), C, "vpp_point_kernel<PK_BICUBIC0"),      # C4: every cubic weight is zero
     ((3840, 2160), (1280, 720), B, "vpp_point_kernel<PK_BILINEAR0"),
     ((1920, 1080), (1280, 720), N, "vpp_point_kernel<PK_NEAREST"),
-    ((3840, 2160), (640, 360), A, "vpp_area_direct_kernel<2"),           # C5: 6 x 6 integer box sums from global memory
-    ((3840, 2160), (960, 540), A, "vpp_area_direct_kernel<1"),           # 4 x 4
+    ((3840, 2160), (640, 360), A, "vpp_area_box_kernel<6,1"),            # C5: 6 x 6 box from contiguous dword runs
+    ((3840, 2160), (960, 540), A, "vpp_area_box_kernel<4,1"),            # 4 x 4
+    ((3840, 2160), (640, 480), A, "vpp_area_box_kernel<6,0"),            # 6 x 4.5: integer horizontally, dyadic rows
+    ((3840, 2160), (768, 432), A, "vpp_area_box_kernel<5,1"),            # 5 x 5
+    ((1920, 1080), (480, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 4 x 3: the vertical ratio is below the direct threshold
     ((1920, 1080), (1280, 720), A, "vpp_area_dyadic_kernel<1,2"),       # 1.5: dyadic weights, LDS
     ((1920, 1080), (960, 540), A, "vpp_area_dyadic_kernel<1,2"),        # 2: LDS kernel below 3.5
     ((1920, 1080), (640, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 3
