@@ -127,21 +127,25 @@ bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_
     return remember(true);
 }
 
-// Is every BICUBIC weight of this request a multiple of 1/16?  (ratios 1.5, 2, 2.5, 4, 0.5, 1.25, 2.25 ...: then the
-// reference's fp64 evaluation is exact and the integer kernel of vpp_bicubic_int.hip reproduces it bit for bit)
-bool bicubic_weights_dyadic(int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
-    struct Memo { int dw, dh, sw, sh; bool res; };
-    static thread_local Memo memo = { 0, 0, 0, 0, false };
-    if (memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
-    auto remember = [&](bool r) { memo = Memo{ dst_w, dst_h, src_w, src_h, r }; return r; };
+// Is every interpolation weight of this request a multiple of 1/16?  (ratios 1.5, 2, 2.5, 4, 0.5, 1.25, 2.25 ...: then the
+// reference's float / double evaluation is exact and the integer kernels -- vpp_bicubic_int.hip, the integer thread tile of
+// the 2x2-tap kernel -- reproduce it bit for bit.)  BILINEAR and BICUBIC share one coordinate formula (src/Resize.cu:276-303,
+// 321-347); the AREA up-scale variant has its own (:221-234).
+bool weights_dyadic(Mode m, int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
+    struct Memo { int m, dw, dh, sw, sh; bool res; };
+    static thread_local Memo memo = { -1, 0, 0, 0, 0, false };
+    const int cls = (m == M_AREA_UP) ? 1 : 0;
+    if (memo.m == cls && memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
+    auto remember = [&](bool r) { memo = Memo{ cls, dst_w, dst_h, src_w, src_h, r }; return r; };
     for (int axis = 0; axis < 2; axis++) {
         const int n = axis ? dst_h : dst_w, lim = axis ? src_h : src_w;
         const float r = axis ? yr : xr;
         for (int o = 0; o < n; o++) { // the chroma grid uses indices 0 .. n/2-1, a subset
             int p;
-            double w;
-            bicubic_axis(o, r, lim, p, w);
-            const double s = w * 16.0;
+            float w;
+            if (m == M_AREA_UP) areaup_axis(o, r, p, w);
+            else bilinear_axis(o, r, lim, p, w); // bicubic_axis: the same fp32 coordinate, widened afterwards
+            const float s = w * 16.0f;
             if (s != std::floor(s)) return remember(false);
         }
     }
@@ -158,7 +162,7 @@ struct Plan {
     int swap_rb = 0;
     size_t out_bytes = 0;
     int point_kind = PK_NONE;
-    int bic_dyadic = 0;
+    int w_dyadic = 0;
     int fourcc = TSVPP_RGB24;
     bool f32 = false;
 };
@@ -181,6 +185,7 @@ struct tsvpp_ctx {
     float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
     int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
+    int bilinear_int = 1;           // TSVPP_BILINEAR_INT: integer thread tile of the 2x2-tap kernel for dyadic weights
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
@@ -246,7 +251,8 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     if (pl.mode == M_NEAREST) pl.point_kind = PK_NEAREST;
     else if ((pl.mode == M_BILINEAR || pl.mode == M_BICUBIC) && all_weights_zero(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h))
         pl.point_kind = pl.mode == M_BILINEAR ? PK_BILINEAR0 : PK_BICUBIC0;
-    pl.bic_dyadic = (pl.mode == M_BICUBIC && pl.point_kind == PK_NONE && bicubic_weights_dyadic(pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h)) ? 1 : 0;
+    pl.w_dyadic = ((pl.mode == M_BICUBIC || pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) && pl.point_kind == PK_NONE &&
+                   weights_dyadic(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h)) ? 1 : 0;
     pl.fourcc = p->fourcc;
     switch (p->fourcc) {
     case TSVPP_RGB24: pl.swap_rb = 0; break;
@@ -286,6 +292,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
@@ -321,7 +328,8 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.bicubic_sep = ctx->bicubic_sep;
     d.bicubic_int_pref = ctx->bicubic_int;
     d.area_box_pref = ctx->area_box;
-    d.bic_dyadic = pl.bic_dyadic;
+    d.w_dyadic = pl.w_dyadic;
+    d.bil_int_pref = ctx->bilinear_int;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;

@@ -74,7 +74,8 @@ struct LaunchDesc {
     int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
     int box_rx, box_ry;     // host: the AREA weight table of that axis is one row of all ones (integer ratio) -> its tap count, else 0
     int area_box_pref, area_box; // contiguous-run box kernel allowed (TSVPP_AREA_BOX) / chosen by launch_fused
-    int bic_dyadic;         // host: every BICUBIC weight of this request is a multiple of 1/16 (integer kernel eligible)
+    int w_dyadic;           // host: every interpolation weight of this BILINEAR / BICUBIC / AREA-up request is a multiple of 1/16
+    int bil_int_pref, bil_int; // integer 2x2-tap thread tile allowed (TSVPP_BILINEAR_INT) / chosen by launch_fused
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused

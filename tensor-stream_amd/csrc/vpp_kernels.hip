@@ -188,6 +188,66 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
+// Integer form of the thread tile for requests whose weights are all multiples of 1/16 (LaunchDesc::bil_int; ratios 1.5,
+// 2, 2.5, 4, 0.5, 1.25 ...: 1080p -> 720p, 4K -> 1080p, 2x up-scales).  The reference's blend
+//     (int)( A (1-wx)(1-wy) + B wx (1-wy) + C wy (1-wx) + D (wx wy) )        (src/Resize.cu:17-23)
+// is then exact in fp32 -- every product has at most 16 significant bits -- so it equals the integer
+//     ( (A wx0 + B wx1) wy0 + (C wx0 + D wx1) wy1 ) >> 8,   wx0 = 16 - 16 wx, wx1 = 16 wx, likewise wy.
+// Per luma value: the two horizontal taps are ONE 16-bit LDS read (A in byte 0, B in byte 1) fed straight into
+// v_dot4_u32_u8 with the column's packed weights; the vertical pair is one v_dot2_u32_u16; the final shift
+// and the conversion for the colour stage are one v_cvt_f32_ubyte1.  5 VALU instructions against ~11 (4 byte -> float
+// conversions + 7 packed multiplies / adds per value); a chroma block's (U, V) come from one 32-bit read (U0 V0 U1 V1) per
+// row with the weights on the even / odd bytes.  Table entries: XEntry::w / YEntry::w carry the packed integer weights.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// top * wy0 + bot * wy1 (both horizontal sums are < 2^12, the weights <= 16): one v_dot2_u32_u16 on (top | bot << 16) -- the
+// 32-bit integer multiplies (v_mul_lo_u32, v_mad_u64_u32) run at a quarter of the VALU rate
+__device__ __forceinline__ uint32_t vpair(uint32_t top, uint32_t bot, uint32_t wyp) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, top | (bot << 16)), __builtin_bit_cast(u16x2, wyp), 0u, false);
+}
+typedef uint16_t lds_u16 __attribute__((aligned(1)));
+typedef uint32_t lds_u32 __attribute__((aligned(1)));
+template <int OUT>
+__device__ __forceinline__ void bilinear_int_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const XEntry *xtab,
+                                                         const XEntry *cxtab, const YEntry *ytab, const YEntry *cytab, int lx, int ly,
+                                                         typename OutT<OUT>::type *out, int i0, int j0) {
+    int xo[PXW], cxo[2];
+    uint32_t xw[PXW], cxw[2];
+    {
+        const uint4 a = *(const uint4 *)(xtab + lx * PXW), b = *(const uint4 *)(xtab + lx * PXW + 2);
+        xo[0] = (int)a.x; xw[0] = a.y; xo[1] = (int)a.z; xw[1] = a.w;
+        xo[2] = (int)b.x; xw[2] = b.y; xo[3] = (int)b.z; xw[3] = b.w;
+        const uint4 c = *(const uint4 *)(cxtab + lx * 2);
+        cxo[0] = (int)c.x; cxw[0] = c.y; cxo[1] = (int)c.z; cxw[1] = c.w;
+    }
+    float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
+    if constexpr (!kLumaOnly<OUT>) {
+        const uint4 cy = *(const uint4 *)(cytab + ly);
+        const uint32_t wyp = cy.z;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t tq = *(const lds_u32 *)(lds_uv + (int)cy.x + cxo[c]), bq = *(const lds_u32 *)(lds_uv + (int)cy.y + cxo[c]);
+            const uint32_t tu = __builtin_amdgcn_udot4(tq, cxw[c], 0u, false), tv = __builtin_amdgcn_udot4(tq, cxw[c] << 8, 0u, false);
+            const uint32_t bu = __builtin_amdgcn_udot4(bq, cxw[c], 0u, false), bv = __builtin_amdgcn_udot4(bq, cxw[c] << 8, 0u, false);
+            const uint32_t su = vpair(tu, bu, wyp), sv = vpair(tv, bv, wyp);
+            Uf[c] = (float)((su >> 8) & 255u);
+            Vf[c] = (float)((sv >> 8) & 255u);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
+        const uint32_t wyp = ye.z;
+#pragma unroll
+        for (int c = 0; c < PXW; c++) {
+            const uint32_t tq = *(const lds_u16 *)(lds_y + (int)ye.x + xo[c]), bq = *(const lds_u16 *)(lds_y + (int)ye.y + xo[c]);
+            const uint32_t tt = __builtin_amdgcn_udot4(tq, xw[c], 0u, false), bb = __builtin_amdgcn_udot4(bq, xw[c], 0u, false);
+            const uint32_t sv = vpair(tt, bb, wyp);
+            Yf[r][c] = (float)((sv >> 8) & 255u);
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+}
+
 template <bool AREAUP, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
@@ -226,23 +286,32 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     for (int e = threadIdx.x; e < ntab; e += nthreads) {
         int p;
         float w;
+        // bil_int: the weight field carries packed integer weights (16 - 16 w, 16 w) instead of the float (see
+        // bilinear_int_thread_tile): luma columns on bytes 0 / 1, chroma pair columns on bytes 0 / 2 (U; V = << 8), rows on
+        // the two 16-bit halves
         if (e < tw) {
             axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
-            xtab[e] = XEntry{ p - f.xlo, w };
+            const uint32_t k16 = (uint32_t)(w * 16.0f);
+            xtab[e] = XEntry{ p - f.xlo, d.bil_int ? __uint_as_float((16u - k16) | (k16 << 8)) : w };
         } else if (e < tw + (tw >> 1)) {
             const int k = e - tw;
             axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
-            cxtab[k] = XEntry{ 2 * (p - f.cxlo), w };
+            const uint32_t k16 = (uint32_t)(w * 16.0f);
+            cxtab[k] = XEntry{ 2 * (p - f.cxlo), d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w };
         } else if (e < tw + (tw >> 1) + th) {
             const int k = e - tw - (tw >> 1);
             axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
+            const uint32_t k16 = (uint32_t)(w * 16.0f);
             const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo; // y + 1 >= height -> same row
-            ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15), w, 0 };
+            ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15),
+                              d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
         } else {
             const int k = e - tw - (tw >> 1) - th;
             axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
+            const uint32_t k16 = (uint32_t)(w * 16.0f);
             const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
-            cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15), w, 0 };
+            cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15),
+                               d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
         }
     }
     if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA chunks have landed
@@ -272,7 +341,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     // paid once per 8 * rpt pixels
     for (int rp = 0; rp < d.rpt; rp++) {
         const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
-        if (i0 < d.dst_h) bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
+        if (i0 >= d.dst_h) break;
+        if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
+        else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
     }
 }
 
@@ -1693,6 +1764,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     LaunchDesc d = din;
     d.rpt = 1;
     d.bicubic_int = 0;
+    d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref && !d.persist) ? 1 : 0;
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
     if (d.nt_stores < 0) { // per-kernel default
         // fp32 outputs: every store instruction of a wave covers whole 128-byte lines (planar: 16 contiguous
@@ -1790,7 +1862,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
-            const bool bint = mode == M_BICUBIC && d.bic_dyadic && d.bicubic_int_pref; // dyadic weights: integer kernel
+            const bool bint = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref; // dyadic weights: integer kernel
             const bool sep = mode == M_BICUBIC && !bint && d.bicubic_sep && sh[1] >= 2;
             const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx >= 2 && d.rx <= 3 && d.ry >= 2 && d.ry <= 3 && d.area2_pref;
             const bool dyadic = mode == M_AREA_DOWN && d.qx && d.qy;
