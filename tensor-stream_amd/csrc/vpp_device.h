@@ -861,6 +861,10 @@ __device__ __forceinline__ float area_quot(uint32_t sum, int sx, int sy, float r
     return __builtin_truncf((float)sum / (float)(sx * sy));
 }
 
+// coordinate-table entries of the 2x2-tap kernel (vpp_bilinear.hip); launch_fused sizes the LDS tables with them
+struct XEntry { int off; float w; };                  // LDS byte offset from the row base, weight
+struct YEntry { int top, bot; float w; int pad; };    // LDS row bases of y and y2, weight
+
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
 } // namespace tsvpp

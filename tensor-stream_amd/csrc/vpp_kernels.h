@@ -113,6 +113,10 @@ hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
 hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
+// The 2x2-tap kernel family (vpp_bilinear.hip): BILINEAR / AREA up-scale, plain or persistent.
+hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &d, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
+                           hipStream_t stream, LaunchInfo *info);
+
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);
 // t.y / t.uv are the (resized or cropped) NV12 planes, t.out the outputs.
 hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int py, int puv, int w, int h, hipStream_t stream);
