@@ -57,6 +57,11 @@ def set_exact_index(on):
     lib().vpp_oracle_set_exact_index(1 if on else 0)
 
 
+def set_contract(bits):
+    """Which a * b + c pairs are evaluated as fused multiply-adds (see vpp_oracle.c: CT_* bits); 0 = none."""
+    lib().vpp_oracle_set_contract(int(bits))
+
+
 def channels(fourcc):
     return float(lib().vpp_oracle_channels(int(fourcc)))
 

@@ -100,6 +100,15 @@ static void crop_stage(const plane_t *s, int l, int t, int r, int b, uint8_t *oy
  * integers).  vpp_oracle_set_exact_index(1) switches the oracle to that stated behaviour, so the
  * deviation has its own expected result and test (tests/test_gpu_edges.py::test_8k_frame); the default (0) stays the
  * faithful restatement, and tests/test_oracle_properties.py shows the two agree wherever the float index is exact. */
+/* Contraction of a * b + c into fused multiply-adds.  The reference is built with nvcc defaults (-fmad=true): which
+ * multiply-add pairs nvcc fused is not visible in its source text, but it IS visible in its test goldens -- the 38 CRC-32
+ * literals replayed by tests/test_reference_crcs.py on the decoded frame pin the pattern (see vpp_oracle_set_contract).
+ * Bits: where an fma replaces the plain operations. */
+enum { CT_COORD = 1, CT_SUM_LEFT = 2, CT_SUM_RIGHT = 4, CT_SUM3 = 8, CT_SUM4 = 16, CT_AREA_DIV = 32, CT_AREA_SUM = 64, CT_AREAUP_COORD = 128,
+       CT_COLOR_INNER = 256, CT_COLOR_OUTER = 512, CT_COLOR_G_LEFT = 1024, CT_COLOR_G_RIGHT = 2048 };
+#define CT_NVCC (CT_COORD | CT_SUM_LEFT | CT_SUM3 | CT_SUM4 | CT_AREA_SUM)
+static int g_contract = CT_NVCC; /* the pattern of the reference's binary: the ONLY one of the 96 (+ colour variants) that reproduces all 38 CRC goldens */
+void vpp_oracle_set_contract(int bits) { g_contract = bits < 0 ? CT_NVCC : bits; }
 static int g_exact_index = 0;
 void vpp_oracle_set_exact_index(int on) { g_exact_index = on; }
 static int bilinear_tap(const uint8_t *d, long len, float x, float y, int xd, int yd, int ls, int w, int h, float wx, float wy) {
@@ -114,17 +123,15 @@ static int bilinear_tap(const uint8_t *d, long len, float x, float y, int xd, in
     int C = rd(d, start + (long)ls * yd, len);
     int D = rd(d, start + (long)ls * yd + xd, len);
     float omx = 1.0f - wx, omy = 1.0f - wy;
-    float t1 = (float)A * omx;
-    t1 = t1 * omy;
-    float t2 = (float)B * wx;
-    t2 = t2 * omy;
-    float t3 = (float)C * wy;
-    t3 = t3 * omx;
-    float t4 = wx * wy;
-    t4 = (float)D * t4;
-    float sum = t1 + t2;
-    sum = sum + t3;
-    sum = sum + t4;
+    float p1 = (float)A * omx, p2 = (float)B * wx, p3 = (float)C * wy, p4 = wx * wy;
+    float sum;
+    if (g_contract & CT_SUM_LEFT) sum = fmaf(p1, omy, p2 * omy);       /* fma(A (1-wx), 1-wy, T2) */
+    else if (g_contract & CT_SUM_RIGHT) sum = fmaf(p2, omy, p1 * omy); /* fma(B wx, 1-wy, T1) */
+    else sum = p1 * omy + p2 * omy;
+    if (g_contract & CT_SUM3) sum = fmaf(p3, omx, sum);
+    else sum = sum + p3 * omx;
+    if (g_contract & CT_SUM4) sum = fmaf((float)D, p4, sum);
+    else sum = sum + (float)D * p4;
     return (int)sum;
 }
 
@@ -242,9 +249,13 @@ static int area_tap(const uint8_t *d, long len, long start, float sx, float sy, 
         for (int j = 0; j < rx; j++) {
             long idx = start + (long)j * stride + (long)i * ls;
             float wgt = px[j] * py[i];
-            div = div + wgt;
-            float v = (float)rd(d, idx, len) * wgt;
-            sum = sum + v;
+            if (g_contract & CT_AREA_DIV) div = fmaf(px[j], py[i], div);
+            else div = div + wgt;
+            if (g_contract & CT_AREA_SUM) sum = fmaf((float)rd(d, idx, len), wgt, sum);
+            else {
+                float v = (float)rd(d, idx, len) * wgt;
+                sum = sum + v;
+            }
         }
     }
     sum = sum / div;
@@ -280,10 +291,16 @@ static int resize_stage(const plane_t *s, int dw, int dh, int type, uint8_t *oy,
 #pragma omp parallel for num_threads(nthreads) schedule(static)
         for (int i = 0; i < dh; i++)
             for (int j = 0; j < dw; j++) {
-                float yf = ((float)(unsigned)i + 0.5f) * yr;
-                yf = yf - 0.5f;
-                float xf = ((float)(unsigned)j + 0.5f) * xr;
-                xf = xf - 0.5f;
+                float yf, xf;
+                if (g_contract & CT_COORD) {
+                    yf = fmaf((float)(unsigned)i + 0.5f, yr, -0.5f);
+                    xf = fmaf((float)(unsigned)j + 0.5f, xr, -0.5f);
+                } else {
+                    yf = ((float)(unsigned)i + 0.5f) * yr;
+                    yf = yf - 0.5f;
+                    xf = ((float)(unsigned)j + 0.5f) * xr;
+                    xf = xf - 0.5f;
+                }
                 int x = (int)floorf(xf), y = (int)floorf(yf);
                 float wx = xf - (float)x, wy = yf - (float)y;
                 if (x < 0) { x = 0; wx = 0; }
@@ -301,10 +318,16 @@ static int resize_stage(const plane_t *s, int dw, int dh, int type, uint8_t *oy,
 #pragma omp parallel for num_threads(nthreads) schedule(static)
         for (int i = 0; i < dh; i++)
             for (int j = 0; j < dw; j++) {
-                float yff = ((float)(unsigned)i + 0.5f) * yr;
-                yff = yff - 0.5f;
-                float xff = ((float)(unsigned)j + 0.5f) * xr;
-                xff = xff - 0.5f;
+                float yff, xff;
+                if (g_contract & CT_COORD) {
+                    yff = fmaf((float)(unsigned)i + 0.5f, yr, -0.5f);
+                    xff = fmaf((float)(unsigned)j + 0.5f, xr, -0.5f);
+                } else {
+                    yff = ((float)(unsigned)i + 0.5f) * yr;
+                    yff = yff - 0.5f;
+                    xff = ((float)(unsigned)j + 0.5f) * xr;
+                    xff = xff - 0.5f;
+                }
                 double yf = (double)yff, xf = (double)xff;
                 int x = (int)floor(xf), y = (int)floor(yf);
                 double wx = xf - x, wy = yf - y;
@@ -376,18 +399,36 @@ static int resize_stage(const plane_t *s, int dw, int dh, int type, uint8_t *oy,
 static void yuv2rgb(int Yv, int U, int V, int *R, int *G, int *B) {
     float yl = (float)Yv - 16.f;
     if (!(yl > 0.f)) yl = 0.f;
-    float yv = yl * 1.163999557f;
-    float rv = 1.5959997177f * (float)(V - 128);
-    rv = rv + 0.5f;
-    *R = clamp255((int)(yv + rv));
-    float bv = 2.017999649f * (float)(U - 128);
-    bv = bv + 0.5f;
-    *B = clamp255((int)(yv + bv));
-    float g1 = -0.812999725f * (float)(V - 128);
-    float g2 = 0.390999794f * (float)(U - 128);
-    float gv = g1 - g2;
+    const float ys = 1.163999557f;
+    float yv = yl * ys;
+    float v = (float)(V - 128), u = (float)(U - 128);
+    float rv, bv, gv;
+    if (g_contract & CT_COLOR_INNER) {
+        rv = fmaf(1.5959997177f, v, 0.5f);
+        bv = fmaf(2.017999649f, u, 0.5f);
+    } else {
+        rv = 1.5959997177f * v;
+        rv = rv + 0.5f;
+        bv = 2.017999649f * u;
+        bv = bv + 0.5f;
+    }
+    if (g_contract & CT_COLOR_G_LEFT) gv = fmaf(-0.812999725f, v, -(0.390999794f * u));
+    else if (g_contract & CT_COLOR_G_RIGHT) gv = fmaf(-0.390999794f, u, -0.812999725f * v);
+    else {
+        float g1 = -0.812999725f * v;
+        float g2 = 0.390999794f * u;
+        gv = g1 - g2;
+    }
     gv = gv + 0.5f;
-    *G = clamp255((int)(yv + gv));
+    if (g_contract & CT_COLOR_OUTER) {
+        *R = clamp255((int)fmaf(yl, ys, rv));
+        *B = clamp255((int)fmaf(yl, ys, bv));
+        *G = clamp255((int)fmaf(yl, ys, gv));
+    } else {
+        *R = clamp255((int)(yv + rv));
+        *B = clamp255((int)(yv + bv));
+        *G = clamp255((int)(yv + gv));
+    }
 }
 
 #define STORE(T, buf, idx, val, norm)                 \

@@ -1,6 +1,7 @@
 // vpp_axis.h -- source coordinate / weight of one output index along one axis, shared by the
 // kernels and by the host (which uses them to recognise requests whose weights are all zero).
-// Plain IEEE, no contraction: host and device evaluate the same correctly rounded operations.
+// Plain IEEE with explicit fused multiply-adds only where the reference's binary has them: host and device evaluate the
+// same correctly rounded operations.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -9,10 +10,12 @@
 
 namespace tsvpp {
 
-// Source coordinate + weight of one axis for BILINEAR (src/Resize.cu:276-303).
+// Source coordinate + weight of one axis for BILINEAR (src/Resize.cu:276-303).  `(j + 0.5f) * xRatio - 0.5f` is ONE fused
+// multiply-add in the reference as nvcc compiles it (fmad is on by default): pinned by the reference's CRC goldens
+// (tests/test_reference_crcs.py; oracle/vpp_oracle.c, "contraction") -- the only floating-point contractions in this
+// library are the ones those goldens demand.
 __host__ __device__ inline void bilinear_axis(int idx, float ratio, int limit, int &p, float &w) {
-    float f = ((float)idx + 0.5f) * ratio;
-    f = f - 0.5f;
+    float f = __builtin_fmaf((float)idx + 0.5f, ratio, -0.5f);
     p = (int)floorf(f);
     w = f - (float)p;
     if (p < 0) { p = 0; w = 0.f; }
@@ -28,8 +31,7 @@ __host__ __device__ inline void areaup_axis(int idx, float ratio, int &p, float 
 }
 // ... for BICUBIC (src/Resize.cu:321-347): fp32 coordinate widened to double.
 __host__ __device__ inline void bicubic_axis(int idx, float ratio, int limit, int &p, double &w) {
-    float ff = ((float)idx + 0.5f) * ratio;
-    ff = ff - 0.5f;
+    float ff = __builtin_fmaf((float)idx + 0.5f, ratio, -0.5f); // the same source expression as BILINEAR's: fused alike
     double f = (double)ff;
     p = (int)floor(f);
     w = f - (double)p;

@@ -81,9 +81,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
             const f2 A = { (float)top[0], (float)top[1] }, B = { (float)top[2], (float)top[3] };
             const f2 C = { (float)bot[0], (float)bot[1] }, D = { (float)bot[2], (float)bot[3] };
             const f2 wx = { cxe[c].w, cxe[c].w }, omx = (f2){ 1.0f, 1.0f } - wx;
-            f2 sum = (A * omx) * omy + (B * wx) * omy;
-            sum = sum + (C * wy) * omx;
-            sum = sum + D * (wx * wy);
+            const f2 sum = bilerp2(A, B, C, D, wx, omx, wy, omy);
             Uf[c] = __builtin_truncf(sum.x);
             Vf[c] = __builtin_truncf(sum.y);
         }
@@ -99,9 +97,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
             const f2 A = { (float)t0[0], (float)t1[0] }, B = { (float)t0[1], (float)t1[1] };
             const f2 C = { (float)b0[0], (float)b1[0] }, D = { (float)b0[1], (float)b1[1] };
             const f2 wx = { xe[2 * p].w, xe[2 * p + 1].w }, omx = (f2){ 1.0f, 1.0f } - wx;
-            f2 sum = (A * omx) * omy + (B * wx) * omy;
-            sum = sum + (C * wy) * omx;
-            sum = sum + D * (wx * wy);
+            const f2 sum = bilerp2(A, B, C, D, wx, omx, wy, omy);
             Yf[r][2 * p] = __builtin_truncf(sum.x);
             Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
         }

@@ -106,7 +106,7 @@ __device__ __forceinline__ f2 areaf_pair(const uint8_t *const t0[RY], const uint
                 sum = p * wgt;
             } else {
                 div = div + wgt;
-                sum = sum + p * wgt;
+                sum = __builtin_elementwise_fma(p, wgt, sum); // colorSum += data * weight is one fma in the reference's binary
             }
         }
     }
@@ -850,7 +850,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
 // ----------------------------------------------------------------------------------------------
 // AREA down-scale with arbitrary (non-dyadic) weights at ratios >= 2, straight from global memory.
 // The reference's float accumulation order (rows outer, taps inner; src/Resize.cu:164-173) is kept
-// per value, so sums are bit-identical: sum += float(tap) * (wx[b] * wy[a]); div += wx[b] * wy[a].
+// per value, so sums are bit-identical: sum = fma(float(tap), wx[b] * wy[a], sum) -- fused, as in the reference's
+// binary -- and div += wx[b] * wy[a] (not fused there: pinned by the CRC goldens).
 // Same memory scheme as vpp_area_direct_kernel (per-pixel aligned dwords + v_alignbyte so that tap 0
 // is byte 0); the weight rows are zero-padded to 4 * NK taps, and a zero weight adds exactly 0 to
 // both accumulators, so four taps are always processed per shifted dword.  Pixel pairs / (U, V)
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
                         const uint32_t q = vv[b >> 1] >> (16 * (b & 1));
                         const float wgt = wv[b] * wy;
                         div = div + wgt;
-                        acc = acc + (f2){ (float)(q & 255), (float)((q >> 8) & 255) } * (f2){ wgt, wgt };
+                        acc = __builtin_elementwise_fma((f2){ (float)(q & 255), (float)((q >> 8) & 255) }, (f2){ wgt, wgt }, acc);
                     }
                 }
             }
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
                         for (int b = 0; b < 4; b++) {
                             const f2 wgt = (f2){ wa[b], wb[b] } * (f2){ wy, wy };
                             div[p] = div[p] + wgt;
-                            acc[p] = acc[p] + (f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) } * wgt;
+                            acc[p] = __builtin_elementwise_fma((f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) }, wgt, acc[p]);
                         }
                     }
                 }
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
                     for (int b = 0; b < 4; b++) {
                         const f2 wgt = (f2){ wk[b], wk[b] } * wy;
                         div = div + wgt;
-                        acc = acc + (f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) } * wgt;
+                        acc = __builtin_elementwise_fma((f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) }, wgt, acc);
                     }
                 }
             }
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
                         const uint32_t qq = vv[b >> 1] >> (16 * (b & 1));
                         const float wgt = wv[b] * wy;
                         div = div + wgt;
-                        acc = acc + (f2){ (float)(qq & 255), (float)((qq >> 8) & 255) } * (f2){ wgt, wgt };
+                        acc = __builtin_elementwise_fma((f2){ (float)(qq & 255), (float)((qq >> 8) & 255) }, (f2){ wgt, wgt }, acc);
                     }
                 }
             }

@@ -1,8 +1,7 @@
 """The reference's CRC-32 goldens for this path (av_crc(AV_CRC_32_IEEE, -1, ...) of the uint8 output of frame 0 of
-tests/resources/bbb_1080x608_420_10.h264).  DORMANT here: no H.264 decoder exists in the image, so the input frame
-cannot be produced.  tests/test_reference_crcs.py replays them the day `tests/golden/bbb_1080x608_frame0.nv12`
-(tight 1080x608 NV12, 984 960 bytes) is dropped in; its two planes are themselves pinned by
-reference tests/src/DecoderTests.cpp:63-65.
+tests/resources/bbb_1080x608_420_10.h264).  tests/test_reference_crcs.py replays them on
+`tests/golden/bbb_1080x608_frame0.nv12` (tight 1080x608 NV12, 984 960 bytes; decoded by tests/golden/make_bbb_frame0.py), whose two
+planes are themselves pinned by reference tests/src/DecoderTests.cpp:63-65.
 
 Fields: (source file:line, fourcc, planes, (dst_w, dst_h), resize, crop (l,t,r,b), accepted CRCs)
 fourcc: 0 Y800 1 RGB24 2 BGR24 3 NV12 4 UYVY 5 YUV444; planes: 0 PLANAR 1 MERGED; resize: 0 NEAREST 1 BILINEAR 2 BICUBIC 3 AREA

@@ -1,6 +1,10 @@
-"""The reference's CRC goldens (tests/golden/reference_crcs.py).  Skipped until the decoded input frame is available
-(`tests/golden/bbb_1080x608_frame0.nv12`): this image has no H.264 decoder.  When present, the frame itself and the
-av_crc restatement are validated first against the decoder test's plane CRCs."""
+"""The reference's 38 CRC-32 goldens (tests/golden/reference_crcs.py), replayed on frame 0 of its own test clip -- the only
+byte-exact pins the reference holds for the interpolating resize kernels (BILINEAR / BICUBIC / AREA at non-dyadic ratios,
+crop + resize, UYVY, YUV444, NV12).  The input frame `tests/golden/bbb_1080x608_frame0.nv12` is decoded from
+tests/resources/bbb_1080x608_420_10.h264 by the intra decoder of tests/golden/h264_intra.py (make_bbb_frame0.py) and is
+itself pinned by the decoder test's plane CRCs (tests/src/DecoderTests.cpp:63-65), which also validates the av_crc
+restatement.  The oracle passes all 38 with exactly one contraction pattern (oracle/vpp_oracle.c, CT_NVCC): that is what pins
+the reference's arithmetic AS COMPILED by nvcc; the HIP kernels reproduce the same 38 literals on the GPU."""
 import os
 
 import numpy as np
