@@ -9,8 +9,9 @@ the batch rotates over enough buffer sets that the working set is > 512 MiB (Inf
 
 Timing: W warm-up steps, then the timed region of EXACTLY K steps -- barrier +
 torch.cuda.synchronize() on both sides, HIP events on the launch stream inside -- is run `--repeats`
-(default 5) times back to back and the MEDIAN region is reported (`ms_per_step` = median wall / K; every
-repeat is listed in `timing.repeats_ms_per_step`).  Max over ranks per repeat.
+times back to back (default max(5, ceil(200 / K)): at least 200 timed iterations) and the MEDIAN region is reported
+(`ms_per_step` = median wall / K; every repeat is listed in `timing.repeats_ms_per_step`: the first regions of a
+short run are slower, the device needs ~20 ms of continuous work to settle its clocks).  Max over ranks per repeat.
 
 Prints ONE JSON line (rank 0).  N>1: one rank per GPU, launched either by torch.distributed.run (RANK /
 WORLD_SIZE in the environment) or by this script itself when `--gpus N` is given without such an environment
@@ -210,7 +211,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps steps is run this many times; the median is reported")
+    ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is run this many times and the median is reported; "
+                    "0 = max(5, ceil(200 / steps)): SURVEY.md 8(d) asks for >= 200 timed iterations and a median of 5")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per 64)")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
@@ -469,7 +471,8 @@ def run(args):
         eng.step(i)
     reps = []
     first = args.warmup
-    for _ in range(max(1, args.repeats)):
+    n_rep = args.repeats if args.repeats > 0 else max(5, -(-200 // max(1, args.steps)))
+    for _ in range(n_rep):
         barrier()
         eng.sync()
         t0 = time.perf_counter()

@@ -15,21 +15,24 @@
  *   colour conversion      reference src/ColorConversion.cu:6-93, 280-330
  *   other FourCC outputs   reference src/ColorConversion.cu:95-278, 331-373
  *
- * Parity status: PINNED for the colour conversion (RGB24/BGR24/Y800/UYVY/YUV444/
- * HSV/NV12) against the reference's own fp32 golden files
- * (tests/resources/test_references/FOURCC_320x240.yuv; see tests/golden/).
- * NEAREST and crop are integer index math.  NEAREST/BILINEAR/BICUBIC/AREA (down-
- * and up-scale) are pinned by the reference's 16 PSNR known-answers
- * (tests/src/VPPTests.cpp:673-911, +-0.01 dB) replayed on its own two JPEGs:
- * all 16 reproduced within 0.010 dB (tests/test_reference_psnr.py).  That pin is
- * statistical: the byte-exact goldens of the interpolating kernels are CRC-32s
- * of a decoded H.264 frame and no decoder exists in this container ("parity
- * unpinned" at the bit level for BILINEAR/BICUBIC/AREA at non-dyadic weights;
- * they are exact by construction at every BASELINE.json ratio).
+ * Parity status: PINNED, bit for bit, on literals the reference itself holds:
+ *   - colour conversion and the other FourCC outputs: its seven fp32 golden files
+ *     (tests/resources/test_references/FOURCC_320x240.yuv; tests/golden/make_golden.py);
+ *   - crop, every resize kernel (non-dyadic ratios included), crop + resize, UYVY / YUV444 / NV12:
+ *     all 38 CRC-32 goldens of tests/src/VPPTests.cpp:134-299 and tests/src/PythonTests.cpp:147-244,
+ *     replayed on frame 0 of tests/resources/bbb_1080x608_420_10.h264 (decoded by
+ *     tests/golden/h264_intra.py; the frame matches tests/src/DecoderTests.cpp:63-65).  They
+ *     single out ONE fused-multiply-add pattern (CT_NVCC below): the reference as nvcc compiled it;
+ *   - the 16 PSNR known-answers (tests/src/VPPTests.cpp:673-911) within 0.010 dB.
+ * Not decidable from those literals, and stated as such in DESIGN.md section 2: the contraction of
+ * the colour conversion's G channel (+-1 on <= 124 of 2^24 triples) and the pow() of the bicubic
+ * coefficients (every variant reproduces every golden).
  *
  * Arithmetic conventions (see DESIGN.md "Arithmetic contract"):
  *   - every float expression is evaluated operation by operation, rounded to
- *     the type the reference source text gives it, NO fused multiply-add;
+ *     the type the reference source text gives it; fused multiply-adds ONLY where
+ *     the reference's CRC goldens demand them (CT_NVCC: coordinates, bilinear sum,
+ *     AREA colorSum);
  *   - float->int is truncation toward zero, round() is half-away-from-zero;
  *   - pow(w,2), pow(w,3) in the bicubic stage are the correctly rounded w*w and (w*w)*w
  *     (see cubic_coeffs; libm pow() selectable for comparison).
