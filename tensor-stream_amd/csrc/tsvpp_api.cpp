@@ -192,6 +192,7 @@ struct tsvpp_ctx {
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
+    int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
     std::mutex area_mu;
     // NV12 intermediates of the two-pass formats (UYVY / YUV444 with a resize): one grow-only slot per stream.  A slot's
     // mutex is held while BOTH passes of a call are enqueued, so calls that share a stream (typically NULL) cannot
@@ -286,6 +287,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_DMA_POW2")) ctx->dma_pow2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
@@ -322,6 +324,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.ablate = ctx->ablate;
     d.persist = ctx->persist;
     d.dma = ctx->dma;
+    d.dma_pow2 = ctx->dma_pow2;
     d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
     d.area_direct_fmin = ctx->area_direct_fmin;

@@ -110,8 +110,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_int_kernel(const Laun
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
     } else {
         stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     }

@@ -201,8 +201,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     if (!(d.ablate & 2))
 #endif
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_magic_uv, nthreads);
     } else {
         stage_planes<2, 1>(d, lds_y, ay, py, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), lds_uv, auv, puv, nuv,
                            min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), nthreads);
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
         YEntry *ytab = (YEntry *)(cxtab + (tw >> 1)), *cytab = ytab + th;
         TileCtx c;
         tile_ctx<MODE>(d, t, tl, ly_, luv_, c);
-        stage_plane_dma(ly_, c.ay, c.py, d.pitch_y, c.ny, c.span_y, d.lds_slot_y, nthreads);
-        stage_plane_dma(luv_, c.auv, c.puv, d.pitch_uv, c.nuv, c.span_uv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(ly_, c.ay, c.py, d.pitch_y, c.ny, c.span_y, d.lds_magic_y, nthreads);
+        stage_plane_dma(luv_, c.auv, c.puv, d.pitch_uv, c.nuv, c.span_uv, d.lds_magic_uv, nthreads);
         const Footprint &f = c.f;
         const int ntab = tw + (tw >> 1) + th + (th >> 1);
         for (int e = threadIdx.x; e < ntab; e += nthreads) {

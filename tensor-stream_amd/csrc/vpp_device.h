@@ -821,38 +821,41 @@ __device__ __forceinline__ void stage_planes(const LaunchDesc &d, uint8_t *lds_y
     }
 }
 
-// LDS-DMA variant (global_load_lds_dwordx4): the chunks go straight from HBM into LDS, no VGPR
-// round trip and no ds_write.  Lane l of a wave instruction lands in LDS slot (wave base + 16 l),
-// so it needs the row pitch to be a power-of-two number of chunks (16 << slot): then the slot of
-// (row r, chunk ch) IS 16 * thread-linear index.  Idle lanes (ch >= cpr, rows past the footprint)
-// fetch a clamped valid chunk into their padding slot.  Rows must be allocated up to a multiple
-// of the rows per round.  The caller waits (vmcnt(0)) and barriers.
+// LDS-DMA variant (global_load_lds_dwordx4): the chunks go straight from HBM into LDS, no VGPR round trip and no
+// ds_write.  Lane l of a wave instruction lands in LDS slot (wave base + 16 l), so one instruction fills 64 CONSECUTIVE
+// 16-byte slots of the plane's chunk array; slot s belongs to row s / cpr, chunk s % cpr (cpr = chunks per row, any
+// number: the division is a multiply-high by the host's `magic` = 2^32 / cpr + 1).  Round 1 padded cpr to a power of two
+// so that the slot of (row, chunk) was the thread index: 19-35 % more LDS per tile and a power-of-two row pitch, i.e. the
+// two half-waves of a wave (neighbouring rows) on the same banks -- 63 % of all LDS cycles of the uint8 2x2-tap kernel
+// were bank-conflict cycles (profiles/r02_u8p_pmc.txt).  Idle lanes (slots past the footprint) fetch the last valid chunk
+// into their padding slot: the plane is allocated up to a multiple of 64 slots.  The caller waits (vmcnt(0)) and barriers.
 __device__ __forceinline__ void stage_plane_dma(uint8_t *lds, const uint8_t *a0, const LdsPlane &lp, int pitch, int nrows, int span,
-                                                int slot_shift, int nthreads) {
-    const int ch = threadIdx.x & ((1 << slot_shift) - 1);
-    const int r0 = threadIdx.x >> slot_shift;
-    const int rstep = nthreads >> slot_shift;
-    const int wave_row0 = (int)((threadIdx.x & ~63u) >> slot_shift); // first row this wave serves in round 0
+                                                uint32_t magic, int nthreads) {
+    const int cpr = lp.lp >> 4;
+    const int total = nrows * cpr;                       // chunk slots of this tile's footprint (uniform)
+    const int wave0 = (int)(threadIdx.x & ~63u);
     if (lp.pm == 0) {
-        // pitch % 16 == 0 (every decoder output): all rows share one misalignment, so everything but the row is
-        // loop-invariant -- the lane's byte offset inside a row is computed once and a round costs an add, a min and one
-        // 64-bit multiply-add instead of ~20 VALU instructions (15 % of all VALU work of the uint8 2x2-tap kernel)
+        // pitch % 16 == 0 (every decoder output): all rows share one misalignment
         const int chmax = (lp.m0 + span - 1) >> 4;
-        const uint8_t *lane = a0 + (16 * min(ch, chmax) - lp.m0);
-        for (int base = 0; base + wave_row0 < nrows; base += rstep) { // wave-uniform trip count
-            const uint32_t rc = (uint32_t)min(base + r0, nrows - 1);
-            const uint8_t *src = lane + (size_t)rc * (size_t)(uint32_t)pitch;
-            uint8_t *dst = lds + ((base << slot_shift) + (int)(threadIdx.x & ~63u)) * 16; // wave-uniform
+        const uint8_t *origin = a0 - lp.m0;
+        for (int base = 0; base + wave0 < total; base += nthreads) { // wave-uniform trip count
+            const uint32_t sl = (uint32_t)min(base + (int)threadIdx.x, total - 1);
+            const uint32_t row = __umulhi(sl, magic);
+            const uint32_t ch = min(sl - row * (uint32_t)cpr, (uint32_t)chmax);
+            const uint8_t *src = origin + ((size_t)row * (size_t)(uint32_t)pitch + 16u * ch);
+            uint8_t *dst = lds + (base + wave0) * 16; // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
         return;
     }
-    for (int base = 0; base + wave_row0 < nrows; base += rstep) {     // wave-uniform trip count
-        const int rc = min(base + r0, nrows - 1);
+    for (int base = 0; base + wave0 < total; base += nthreads) {
+        const uint32_t sl = (uint32_t)min(base + (int)threadIdx.x, total - 1);
+        const int rc = (int)__umulhi(sl, magic);
+        const int ch = (int)sl - rc * cpr;
         const int mis = (lp.m0 + rc * lp.pm) & 15;
         const int chmax = (mis + span - 1) >> 4;
         const uint8_t *src = a0 + (size_t)rc * (size_t)pitch - mis + 16 * min(ch, chmax);
-        uint8_t *dst = lds + ((base << slot_shift) + (int)(threadIdx.x & ~63u)) * 16; // wave-uniform
+        uint8_t *dst = lds + (base + wave0) * 16; // wave-uniform
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
 }

@@ -56,7 +56,8 @@ struct LaunchDesc {
     // LDS staging bounds (staged kernel): max source bytes per row, rows, 16-byte chunks per row
     int lds_span_y, lds_rows_y, lds_cpr_y;
     int lds_span_uv, lds_rows_uv, lds_cpr_uv;
-    int lds_slot_y, lds_slot_uv; // log2 of the lanes serving one staged row
+    int lds_slot_y, lds_slot_uv; // log2 of the lanes serving one staged row (register-staged path)
+    uint32_t lds_magic_y, lds_magic_uv; // 2^32 / chunks-per-row + 1 (LDS-DMA path: slot -> row by multiply-high)
     int point_kind;   // PointKind: >= 0 when the request is a pure point sampler (host decides, see vpp_axis.h)
     int in_aligned4;  // every frame's (crop-adjusted) plane pointers and both pitches are multiples of 4
     int force_gather; // debugging / A-B: 1 = always use the global-gather kernel
@@ -68,6 +69,7 @@ struct LaunchDesc {
     float area_direct_min;  // use it when both ratios are >= this (0 = never)
     float area_direct_fmin; // the same for the float-weight direct kernel
     int rpt_pref;           // preferred row pairs per thread for the 2x2-tap kernel (TSVPP_RPT)
+    int dma_pow2;           // A/B only: LDS-DMA rows padded to a power-of-two number of chunks (the round-1 layout)
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)

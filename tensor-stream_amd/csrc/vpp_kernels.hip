@@ -63,8 +63,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const Lau
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_raw, ay, s.py_, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, s.puv_, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_raw, ay, s.py_, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, s.puv_, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         stage_planes<4, 2>(d, lds_raw, ay, s.py_, ny, spy, lds_uv, auv, s.puv_, nuv, spuv, nthreads);
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_areaf_kernel(const LaunchDesc
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
     } else {
         stage_planes<2, 1>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     }
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_kernel(const LaunchDe
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
     } else {
         stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     }
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_sep_kernel(const Laun
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
     } else {
         stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     }
@@ -606,8 +606,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_dyadic_kernel(const Laun
     // the DMA path that normally runs needs fewer than 100.)
     const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
     if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_slot_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_slot_uv, nthreads);
+        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
+        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
     } else
         stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
     const int ntab = tw + (tw >> 1) + th + (th >> 1) + d.lds_rows_y + d.lds_rows_uv;
@@ -1505,12 +1505,13 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                 c.rows_uv = rows_uv;
                 c.dma = (layout == 1 && nthreads >= 64) ? 1 : 0;
                 if (layout == 1 && !c.dma) return c;
-                if (c.dma) { // power-of-two chunks per row, rows padded to whole rounds
+                if (c.dma && d.dma_pow2) { // round-1 layout (A/B: TSVPP_DMA_POW2=1): power-of-two chunks per row
                     c.cpr_y = 1 << slot_shift_for(c.cpr_y);
                     c.cpr_uv = 1 << slot_shift_for(c.cpr_uv);
-                    const int rs_y = nthreads / c.cpr_y, rs_uv = nthreads / c.cpr_uv;
-                    c.rows_y = (rows_y + rs_y - 1) / rs_y * rs_y;
-                    c.rows_uv = (rows_uv + rs_uv - 1) / rs_uv * rs_uv;
+                }
+                if (c.dma) { // a wave instruction fills 64 consecutive chunk slots: the plane is allocated up to a multiple of 64 slots
+                    c.rows_y = ((rows_y * c.cpr_y + 63) / 64 * 64 + c.cpr_y - 1) / c.cpr_y;
+                    c.rows_uv = ((rows_uv * c.cpr_uv + 63) / 64 * 64 + c.cpr_uv - 1) / c.cpr_uv;
                 }
                 const size_t cols = (size_t)sh[0] * PXW, rows = (size_t)sh[1] * PXH * rpt;
                 size_t need = (size_t)16 * ((size_t)c.rows_y * c.cpr_y + (size_t)c.rows_uv * c.cpr_uv);
@@ -1572,6 +1573,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                 d.lds_rows_uv = best.rows_uv;
                 d.lds_cpr_uv = best.cpr_uv;
                 d.lds_slot_uv = slot_shift_for(best.cpr_uv);
+                d.lds_magic_y = 0xFFFFFFFFu / (uint32_t)best.cpr_y + 1u;
+                d.lds_magic_uv = 0xFFFFFFFFu / (uint32_t)best.cpr_uv + 1u;
                 d.dma = best.dma;
                 if (mode == M_BICUBIC) d.bicubic_sep = sep ? 1 : 0;
                 d.bicubic_int = bint ? 1 : 0;
