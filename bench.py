@@ -433,7 +433,12 @@ def run(args):
     spec, name = resolve_spec(args)
     src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
     dist = None
+    out_fd = None
     if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on one GPU
+        # RCCL prints a version banner on stdout: keep stdout for the ONE JSON line (everything else goes to stderr)
+        sys.stdout.flush()
+        out_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -542,7 +547,11 @@ def run(args):
                 res["cpu_baseline"] = cpu_baseline(spec, budget_s=args.cpu_budget, tight_pitch=args.tight_pitch)
             except Exception as e:
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "swscale": "unavailable in image"}
-        print(json.dumps(res), flush=True)
+        if out_fd is not None:
+            sys.stdout.flush()
+            os.write(out_fd, (json.dumps(res) + "\n").encode())
+        else:
+            print(json.dumps(res), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

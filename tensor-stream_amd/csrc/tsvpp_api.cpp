@@ -102,12 +102,29 @@ bool build_area_rows(float scale, std::vector<float> &tab, int &rows, int &taps)
 
 // Is every interpolation weight of this request zero?  (odd integer ratios; then BILINEAR and
 // BICUBIC reduce exactly to their centre tap, src/Resize.cu:17-23, 45-50 with w = 0)
+// Per-thread memo of a geometry predicate: a consumer thread converts thousands of frames with a handful of geometries (a
+// full scan of a dyadic request costs dst_w + dst_h coordinate evaluations, ~20 us -- several single-frame conversions).
+struct GeomMemo {
+    struct Entry { int cls, dw, dh, sw, sh; bool res; };
+    Entry e[16];
+    int n = 0, next = 0;
+    const bool *find(int cls, int dw, int dh, int sw, int sh) const {
+        for (int i = 0; i < n; i++)
+            if (e[i].cls == cls && e[i].dw == dw && e[i].dh == dh && e[i].sw == sw && e[i].sh == sh) return &e[i].res;
+        return nullptr;
+    }
+    bool put(int cls, int dw, int dh, int sw, int sh, bool res) {
+        e[next] = Entry{ cls, dw, dh, sw, sh, res };
+        next = (next + 1) % 16;
+        if (n < 16) n++;
+        return res;
+    }
+};
+
 bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
-    // one-entry memo: a stream converts thousands of frames with the same geometry
-    struct Memo { int m, dw, dh, sw, sh; bool res; };
-    static thread_local Memo memo = { -1, 0, 0, 0, 0, false };
-    if (memo.m == (int)m && memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
-    auto remember = [&](bool r) { memo = Memo{ (int)m, dst_w, dst_h, src_w, src_h, r }; return r; };
+    static thread_local GeomMemo memo;
+    if (const bool *hit = memo.find((int)m, dst_w, dst_h, src_w, src_h)) return *hit;
+    auto remember = [&](bool r) { return memo.put((int)m, dst_w, dst_h, src_w, src_h, r); };
     for (int axis = 0; axis < 2; axis++) {
         const int n = axis ? dst_h : dst_w, lim = axis ? src_h : src_w;
         const float r = axis ? yr : xr;
@@ -132,11 +149,10 @@ bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_
 // the 2x2-tap kernel -- reproduce it bit for bit.)  BILINEAR and BICUBIC share one coordinate formula (src/Resize.cu:276-303,
 // 321-347); the AREA up-scale variant has its own (:221-234).
 bool weights_dyadic(Mode m, int dst_w, int dst_h, float xr, float yr, int src_w, int src_h) {
-    struct Memo { int m, dw, dh, sw, sh; bool res; };
-    static thread_local Memo memo = { -1, 0, 0, 0, 0, false };
+    static thread_local GeomMemo memo;
     const int cls = (m == M_AREA_UP) ? 1 : 0;
-    if (memo.m == cls && memo.dw == dst_w && memo.dh == dst_h && memo.sw == src_w && memo.sh == src_h) return memo.res;
-    auto remember = [&](bool r) { memo = Memo{ cls, dst_w, dst_h, src_w, src_h, r }; return r; };
+    if (const bool *hit = memo.find(cls, dst_w, dst_h, src_w, src_h)) return *hit;
+    auto remember = [&](bool r) { return memo.put(cls, dst_w, dst_h, src_w, src_h, r); };
     for (int axis = 0; axis < 2; axis++) {
         const int n = axis ? dst_h : dst_w, lim = axis ? src_h : src_w;
         const float r = axis ? yr : xr;
