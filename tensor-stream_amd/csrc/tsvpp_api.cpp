@@ -205,6 +205,7 @@ struct tsvpp_ctx {
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
+    int area_cols_rows = 0;         // TSVPP_AREA_COLS_ROWS: 8 or 32 (0: by tap count)
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
@@ -314,6 +315,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_COLS_ROWS")) ctx->area_cols_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
 }
@@ -352,6 +354,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;
+    d.area_cols_rows = ctx->area_cols_rows;
     d.num_cus = ctx->num_cus;
 }
 

@@ -82,6 +82,7 @@ struct LaunchDesc {
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
     int area_cols_pref, area_cols; // column-per-lane float AREA kernel allowed (TSVPP_AREA_COLS) / chosen by launch_fused
+    int area_cols_rows;     // its tile height: 8 (one row pair per wave) or 32 (TSVPP_AREA_COLS_ROWS)
     int col0;               // first output column of this launch (0; dst_w & ~3 in the row-tail launch of widths 4 k + 2)
     int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled

@@ -999,10 +999,15 @@ __device__ __forceinline__ void cols_load(const uint8_t *plane, uint32_t pm, uin
     }
 }
 
-template <int NK, int OUT>
+// TH = 32: the round-1 tile (each wave samples 8 rows: 8 values per lane, as many as a 2 x 4 thread tile).  TH = 8 (round 2):
+// each wave samples ONE row pair -- four times as many waves for the same frame.  At these ratios a value is a serial chain
+// of 45-100 taps behind strided loads, and 1080p -> 224 x 224 x 64 frames is only 7168 waves of the round-1 shape: on average
+// 2.2 resident waves per SIMD (profiles/r02_a224_pmc.txt), i.e. latency-bound by lack of parallelism, not by VALU or HBM.
+template <int NK, int TH, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
-    constexpr int TW = 64, TH = 32; // output tile of the workgroup (tx = ty = 16 thread tiles)
+    constexpr int TW = 64; // output tile of the workgroup: 64 columns x TH rows (16 x TH / 2 thread tiles), always 256 threads
+    static_assert(TH == 32 || TH == 8, "tile height");
     __shared__ __attribute__((aligned(16))) float yt[TH][TW];
     __shared__ __attribute__((aligned(16))) f2 uvt[TH / 2][TW / 2];
     const TileId id = decode_tile(d);
@@ -1019,8 +1024,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
         vf4 wx[NK];
 #pragma unroll
         for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
-        for (int rp = 0; rp < 4; rp++) {
-            const int r0 = 8 * wave + 2 * rp;
+        for (int rp = 0; rp < TH / 8; rp++) {
+            const int r0 = (TH / 4) * wave + 2 * rp;
             const int iA = min(i_first + r0, d.dst_h - 1), iB = min(i_first + r0 + 1, d.dst_h - 1);
             const float *wyA = d.paty4 + (iA % d.ny) * 4 * d.nky, *wyB = d.paty4 + (iB % d.ny) * 4 * d.nky;
             const int yA = (int)(d.yr * (float)iA), yB = (int)(d.yr * (float)iB);
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
             yt[r0 + 1][lane] = __builtin_truncf(acc.y / div.y);
         }
     }
-    if (!d.luma_only) { // chroma: lanes 0-31 / 32-63 = the 32 chroma columns of two chroma rows; (U, V) as a pair
+    if (!d.luma_only && (TH == 32 || wave < 2)) { // chroma: lanes 0-31 / 32-63 = the 32 chroma columns of two chroma rows; (U, V) as a pair
         const int cw = d.dst_w >> 1, chh = d.dst_h >> 1;
         const int cj = min((j_first >> 1) + (lane & 31), cw - 1);
         const int x0 = 2 * (int)(d.xr * (float)cj);
@@ -1054,8 +1059,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
         vf4 wx[NK];
 #pragma unroll
         for (int k = 0; k < NK; k++) wx[k] = *(const vf4a4 *)(wxrow + 4 * k);
-        for (int q = 0; q < 2; q++) {
-            const int cr = 4 * wave + 2 * q + (lane >> 5);
+        for (int q = 0; q < (TH == 32 ? 2 : 1); q++) {
+            const int cr = (TH == 32 ? 4 * wave + 2 * q : 2 * wave) + (lane >> 5);
             const int ci = min((i_first >> 1) + cr, chh - 1);
             const float *wyrow = d.paty4 + (ci % d.ny) * 4 * d.nky;
             const int y0 = (int)(d.yr * (float)ci);
@@ -1096,6 +1101,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
     __syncthreads();
 
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    if (ly >= TH / 2) return; // TH = 8: one wave converts and stores the 64 x 8 tile
     const int j0 = j_first + lx * PXW, i0 = i_first + ly * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
     if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
@@ -1306,9 +1312,16 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 return info ? hipSuccess : hipGetLastError();
             }
             if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // the same, one output column per lane
-                if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, OUT>", (vpp_area_cols_kernel<1, OUT>), grid, block, 0);
-                else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, OUT>", (vpp_area_cols_kernel<2, OUT>), grid, block, 0);
-                else TSVPP_LAUNCH("vpp_area_cols_kernel<3, OUT>", (vpp_area_cols_kernel<3, OUT>), grid, block, 0);
+                const dim3 cblock(MAX_THREADS); // 256 threads whatever the tile height
+                if (d.area_cols_rows == 32) {
+                    if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 32, OUT>", (vpp_area_cols_kernel<2, 32, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
+                } else {
+                    if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 8, OUT>", (vpp_area_cols_kernel<1, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 8, OUT>", (vpp_area_cols_kernel<2, 8, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
+                }
                 return info ? hipSuccess : hipGetLastError();
             }
             if (vec && d.area_direct == 2 && !d.force_gather) { // large non-dyadic ratios: float sums straight from global memory
@@ -1425,13 +1438,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.area_direct = 0;
     // integer horizontal ratio (one all-ones weight row), 4-byte aligned planes and pitches: the box kernel's contiguous runs
     d.area_box = (d.area_direct == 1 && d.area_box_pref && d.box_rx >= 4 && d.box_rx <= 8 && d.box_rx == d.rx && d.in_aligned4 && d.ry <= 8) ? 1 : 0;
-    // measured (tools/ab: TSVPP_AREA_COLS=0/1/2): the column-per-lane kernel wins at 5-8 horizontal taps (1080p -> 300^2
-    // +17 %, -> 416^2 +34 %, 4K -> 608x342 +11 %), is even at 2-4 and loses at 9+ (1080p -> 224^2 -6 %: 102 VGPRs and
-    // half-empty 64 x 32 tiles); 2 = always
-    d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx == 2))) ? 1 : 0;
-    if (d.area_cols) { // fixed workgroup: 16 x 16 thread tiles = 64 columns x 32 rows
+    // measured (round 2, profiles/r02_area_cols_ab.txt; TSVPP_AREA_COLS=0/1/2, TSVPP_AREA_COLS_ROWS=8/32): the column-per-lane
+    // kernel wins from 5 horizontal taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 %, 4K -> 608x342 +11 %, and with 8-row tiles
+    // (four times the waves) also at 9-12 taps: 1080p -> 224^2 +11 % -- and is even at 2-4 taps
+    d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
+    if (d.area_cols_rows != 8 && d.area_cols_rows != 32) d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
+    if (d.area_cols) { // fixed workgroup of 256 threads; tile = 16 x (rows / 2) thread tiles = 64 columns x 32 or 8 rows
         d.tx = 16;
-        d.ty = 16;
+        d.ty = d.area_cols_rows / 2;
     }
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
