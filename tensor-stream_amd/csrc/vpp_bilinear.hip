@@ -175,6 +175,77 @@ __device__ __forceinline__ void bilinear_int_thread_tile(const LaunchDesc &d, co
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
+
+// Window form of the integer thread tile (LaunchDesc::bil_int == 2: dyadic weights and a horizontal ratio <= 2).  The byte form
+// above issues 48 ds_read_u8 per thread tile, and at a lane stride of 6 bytes (ratio 1.5) every one of them is a two-way bank
+// conflict: the LDS pipe, not the VALU, set the pace of the uint8 outputs.  Here each source row of the thread tile is read ONCE
+// as three ALIGNED dwords (ds_read2_b32 + ds_read_b32), two v_alignbyte_b32 shift them into the 8 bytes that start at the
+// thread's first tap, and one v_perm_b32 per output column -- its selector depends on the column only, so it is built once per
+// thread -- picks (A, 0, B, 0) for v_dot4_u32_u8.  With ratio <= 2 the four columns' taps span at most 8 bytes (luma: column 3
+// starts <= 6 bytes after column 0; chroma: U0 V0 U1 V1 of the second block end <= 8 bytes after the first block's U0).
+// LDS instructions per thread tile: 18 instead of 60; the arithmetic after the perm is unchanged (same integers as the byte form).
+struct TapWindow {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ TapWindow window8(const uint8_t *lds, int a) {
+    const uint32_t *q = (const uint32_t *)(lds + (a & ~3));
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t s = (uint32_t)a & 3u;
+    return TapWindow{ __builtin_amdgcn_alignbyte(d1, d0, s), __builtin_amdgcn_alignbyte(d2, d1, s) };
+}
+// this thread's columns: first tap offset, per-column selectors and packed weights (constant over the thread's row pairs)
+struct WinColumns {
+    int xo0, cxo0;
+    uint32_t sel[PXW], w[PXW], csel[2], cw[2];
+};
+__device__ __forceinline__ WinColumns win_columns(const XEntry *xtab, const XEntry *cxtab, int lx) {
+    WinColumns k;
+    const uint4 a = *(const uint4 *)(xtab + lx * PXW), b = *(const uint4 *)(xtab + lx * PXW + 2);
+    const uint4 c = *(const uint4 *)(cxtab + lx * 2);
+    k.xo0 = (int)a.x;
+    k.cxo0 = (int)c.x;
+    const uint32_t rel[PXW] = { 0u, a.z - a.x, b.x - a.x, b.z - a.x };
+    k.w[0] = a.y; k.w[1] = a.w; k.w[2] = b.y; k.w[3] = b.w;
+#pragma unroll
+    for (int i = 0; i < PXW; i++) k.sel[i] = rel[i] * 0x00010001u + 0x0c010c00u; // bytes (rel, 0x0c -> zero, rel + 1, zero)
+    k.csel[0] = 0x0c020c00u;                                                     // U taps at +0 / +2 (V: every selector + 1)
+    k.csel[1] = (c.z - c.x) * 0x00010001u + 0x0c020c00u;
+    k.cw[0] = c.y; k.cw[1] = c.w;
+    return k;
+}
+template <int OUT>
+__device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const WinColumns &k,
+                                                         const YEntry *ytab, const YEntry *cytab, int ly, typename OutT<OUT>::type *out, int i0,
+                                                         int j0) {
+    float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
+    if constexpr (!kLumaOnly<OUT>) {
+        const uint4 cy = *(const uint4 *)(cytab + ly);
+        const TapWindow T = window8(lds_uv, (int)cy.x + k.cxo0), B = window8(lds_uv, (int)cy.y + k.cxo0);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t su = k.csel[c], sv = su + 0x00010001u;
+            const uint32_t tu = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, su), k.cw[c], 0u, false);
+            const uint32_t tv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, sv), k.cw[c], 0u, false);
+            const uint32_t bu = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, su), k.cw[c], 0u, false);
+            const uint32_t bv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, sv), k.cw[c], 0u, false);
+            Uf[c] = (float)((vpair(tu, bu, cy.z) >> 8) & 255u);
+            Vf[c] = (float)((vpair(tv, bv, cy.z) >> 8) & 255u);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
+        const TapWindow T = window8(lds_y, (int)ye.x + k.xo0), B = window8(lds_y, (int)ye.y + k.xo0);
+#pragma unroll
+        for (int c = 0; c < PXW; c++) {
+            const uint32_t tt = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, k.sel[c]), k.w[c], 0u, false);
+            const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, k.sel[c]), k.w[c], 0u, false);
+            Yf[r][c] = (float)((vpair(tt, bb, ye.z) >> 8) & 255u);
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+}
+
 template <bool AREAUP, int OUT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
@@ -265,6 +336,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     // thread tile = 4 columns x (2 * rpt) rows: the tile decode, the staging set-up and the table build are
     // paid once per 8 * rpt pixels
+    if (d.bil_int == 2) {
+        const WinColumns k = win_columns(xtab, cxtab, lx);
+        for (int rp = 0; rp < d.rpt; rp++) {
+            const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
+            if (i0 >= d.dst_h) break;
+            bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
+        }
+        return;
+    }
     for (int rp = 0; rp < d.rpt; rp++) {
         const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
         if (i0 >= d.dst_h) break;

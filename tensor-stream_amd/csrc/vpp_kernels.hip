@@ -1388,6 +1388,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.rpt = 1;
     d.bicubic_int = 0;
     d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref && !d.persist) ? 1 : 0;
+    // window form (one aligned 12-byte read per source row instead of byte reads): the four columns of a thread must span <= 8
+    // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form
+    if (d.bil_int && d.bil_int_pref != 2 && d.xr <= 2.0f) d.bil_int = 2;
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
     if (d.nt_stores < 0) { // per-kernel default
         // fp32 outputs: every store instruction of a wave covers whole 128-byte lines (planar: 16 contiguous
