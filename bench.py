@@ -215,6 +215,8 @@ def parse_args(argv=None):
                     "0 = max(5, ceil(200 / steps)): SURVEY.md 8(d) asks for >= 200 timed iterations and a median of 5")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per 64)")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--alias", type=int, default=0, help="DIAGNOSTIC (not a measurement of the path): bit 0 = all frames of a launch read one "
+                    "input frame, bit 1 = all write one output buffer, so that reads / writes stay in cache; separates issue-bound from memory-bound kernels")
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets")
     ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
@@ -328,6 +330,10 @@ class GpuEngine:
             ys = torch.randint(0, 256, (B, src_h, pitch), dtype=torch.uint8, device="cuda", generator=g)
             uvs = torch.randint(0, 256, (B, src_h // 2, pitch), dtype=torch.uint8, device="cuda", generator=g)
             out = self.vpp._alloc(self.fp.parameters, src_w, src_h, B)
+            if args.alias & 1:   # diagnostic: every frame of the set reads frame 0 (reads stay in L2 / Infinity Cache)
+                ys, uvs = ys[:1].expand(B, -1, -1), uvs[:1].expand(B, -1, -1)
+            if args.alias & 2:   # diagnostic: every frame writes frame 0's buffer (writes combine in L2)
+                out = out[:1].expand(B, *([-1] * (out.dim() - 1)))
             self.sets.append((ys, uvs, out))
         self.ws_mib = sum(a.numel() * a.element_size() for s in self.sets for a in s) / 2**20
 
@@ -525,6 +531,8 @@ def run(args):
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if args.alias:  # not a measurement of the path: the frames of a launch share buffers
+            res["data"] = "DIAGNOSTIC: aliased buffers (--alias %d)" % args.alias
         try:  # graded on the ROI formula; touched_bytes explains fractions > 1 of the sparse samplers
             tb = touched_bytes(spec)
             res["roofline"]["touched_bytes"] = tb

@@ -35,6 +35,7 @@ struct AreaTable {
     int uniform_sum = 0;      // > 0: every row of the integer table has this weight sum
     float *dev4 = nullptr;    // the float rows zero-padded to a multiple of four taps
     int nk = 0;               // taps4 = 4 * nk
+    std::shared_ptr<std::vector<float>> host4; // host copy of dev4 (divisor tables of the float AREA kernels)
 };
 
 // Integer form of a weight table if all weights are dyadic: w * 2^shift integral, shift <= 6.
@@ -191,6 +192,7 @@ struct tsvpp_ctx {
     std::mutex stream_mu;
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
+    std::map<uint64_t, float *> area_div; // divisor tables, keyed by both scales' bit patterns (null: too large, not built)
     int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
     int nt_stores = -1, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
     int ablate = 0;
@@ -205,6 +207,8 @@ struct tsvpp_ctx {
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
+    int area_divtab = 1;            // TSVPP_AREA_DIVTAB: host-built divisor table for the float AREA kernels
+    int area_cols_lds = 1;          // TSVPP_AREA_COLS_LDS: stage the column-per-lane AREA kernel's footprint in LDS
     int area_cols_rows = 0;         // TSVPP_AREA_COLS_ROWS: 8 or 32 (0: by tap count)
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
@@ -312,6 +316,8 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_COLS_LDS")) ctx->area_cols_lds = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
@@ -351,6 +357,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_box_pref = ctx->area_box;
     d.w_dyadic = pl.w_dyadic;
     d.bil_int_pref = ctx->bilinear_int;
+    d.area_cols_lds_pref = ctx->area_cols_lds;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;
@@ -388,6 +395,7 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
         std::vector<float> pad((size_t)t.rows * 4 * t.nk, 0.0f);
         for (int r = 0; r < t.rows; r++)
             for (int k = 0; k < t.taps; k++) pad[(size_t)r * 4 * t.nk + k] = tab[(size_t)r * t.taps + k];
+        t.host4 = std::make_shared<std::vector<float>>(pad);
         if (hipMalloc((void **)&t.dev4, pad.size() * sizeof(float)) != hipSuccess ||
             hipMemcpy(t.dev4, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(t.dev);
@@ -408,6 +416,53 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     }
     ctx->area[key] = t;
     out = t;
+    return TSVPP_OK;
+}
+
+// Divisor table of the float AREA kernels that keep one output column per lane (vpp_area_cols.hip): the reference
+// accumulates `divide += weight` next to `colorSum = fma(data, weight, colorSum)` (src/Resize.cu:160-178), and the sum depends
+// only on the column's and the row's weight patterns -- nx * ny distinct values per geometry.  Built here with the kernel's
+// own fp32 operations in the kernel's order (product rounded to fp32, then added; rows outer, the 4 * nk zero-padded taps
+// inner), so the kernel can load the divisor instead of spending one add per tap and lane on it.  Tables above 2^18 entries
+// are not built (the kernel then sums the weights itself).
+#pragma clang fp contract(off)
+int get_area_div(tsvpp_ctx *ctx, float xr, float yr, const AreaTable &tx, const AreaTable &ty, const float *&out) {
+    out = nullptr;
+    uint32_t kx, ky;
+    std::memcpy(&kx, &xr, 4);
+    std::memcpy(&ky, &yr, 4);
+    const uint64_t key = ((uint64_t)kx << 32) | ky;
+    std::lock_guard<std::mutex> lk(ctx->area_mu);
+    auto it = ctx->area_div.find(key);
+    if (it != ctx->area_div.end()) {
+        out = it->second;
+        return TSVPP_OK;
+    }
+    float *dev = nullptr;
+    if (tx.host4 && ty.host4 && (long)tx.rows * ty.rows <= (1L << 18)) {
+        const int tx4 = 4 * tx.nk, ty4 = 4 * ty.nk;
+        std::vector<float> tab((size_t)tx.rows * ty.rows);
+        for (int jx = 0; jx < tx.rows; jx++) {
+            const float *wx = tx.host4->data() + (size_t)jx * tx4;
+            for (int iy = 0; iy < ty.rows; iy++) {
+                const float *wy = ty.host4->data() + (size_t)iy * ty4;
+                volatile float div = 0.0f; // volatile: every product and every partial sum is rounded to fp32, as on the device
+                for (int a = 0; a < ty.taps; a++)
+                    for (int k = 0; k < tx4; k++) {
+                        volatile float wgt = wx[k] * wy[a];
+                        div = div + wgt;
+                    }
+                tab[(size_t)jx * ty.rows + iy] = div;
+            }
+        }
+        if (hipMalloc((void **)&dev, tab.size() * sizeof(float)) != hipSuccess) return TSVPP_ERROR;
+        if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(dev);
+            return TSVPP_ERROR;
+        }
+    }
+    ctx->area_div[key] = dev;
+    out = dev;
     return TSVPP_OK;
 }
 
@@ -552,6 +607,8 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
         if (a.second.qdev) (void)hipFree(a.second.qdev);
         if (a.second.dev4) (void)hipFree(a.second.dev4);
     }
+    for (auto &a : ctx->area_div)
+        if (a.second) (void)hipFree(a.second);
     }
     delete ctx;
 }
@@ -674,6 +731,10 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.nkx = tx.nk;
         d.paty4 = ty.dev4;
         d.nky = ty.nk;
+        if (!(tx.qdev && ty.qdev) && ctx->area_divtab) { // float-weight kernels only
+            sts = get_area_div(ctx, pl.xr, pl.yr, tx, ty, d.area_div);
+            if (sts != TSVPP_OK) return sts;
+        }
         if (tx.qdev && ty.qdev && dyadic_usable(pl.xr, pl.yr, tx.shift, ty.shift)) {
             d.qx = tx.qdev;
             d.qy = ty.qdev;
@@ -822,6 +883,7 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
             (axis ? d.nky : d.nkx) = (taps + 3) / 4;
         }
         d.patx = d.paty = d.patx4 = d.paty4 = dummy_f;
+        if (!(dyadic[0] && dyadic[1]) && tmp.area_divtab && (long)d.nx * d.ny <= (1L << 18)) d.area_div = dummy_f; // as get_area_div would
         if (dyadic[0] && dyadic[1] && dyadic_usable(pl.xr, pl.yr, shift[0], shift[1])) {
             d.qx = d.qy = &dummy_q;
             d.box_rx = (d.nx == 1 && shift[0] == 0 && uniform[0] == d.rx) ? d.rx : 0;

@@ -190,8 +190,8 @@ struct TapWindow {
 __device__ __forceinline__ TapWindow window8(const uint8_t *lds, int a) {
     const uint32_t *q = (const uint32_t *)(lds + (a & ~3));
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    const uint32_t s = (uint32_t)a & 3u;
-    return TapWindow{ __builtin_amdgcn_alignbyte(d1, d0, s), __builtin_amdgcn_alignbyte(d2, d1, s) };
+    // v_alignbyte_b32 shifts by 8 * (operand & 3) (probed, tools/dbg_cvt.hip): the address itself is the shift operand
+    return TapWindow{ __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)a), __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)a) };
 }
 // this thread's columns: first tap offset, per-column selectors and packed weights (constant over the thread's row pairs)
 struct WinColumns {
@@ -244,6 +244,12 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+}
+
+// table weight field: the float weight, or for the integer tiles the packed pair (16 - 16 w) | (16 w) << 16
+__device__ __forceinline__ float table_weight(const LaunchDesc &d, float w) {
+    const uint32_t k16 = (uint32_t)(w * 16.0f);
+    return d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w;
 }
 
 template <bool AREAUP, int OUT>
@@ -416,21 +422,21 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
             float w;
             if (e < tw) {
                 axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
-                xtab[e] = XEntry{ p - f.xlo, w };
+                xtab[e] = XEntry{ p - f.xlo, table_weight(d, w) };
             } else if (e < tw + (tw >> 1)) {
                 const int k = e - tw;
                 axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
-                cxtab[k] = XEntry{ 2 * (p - f.cxlo), w };
+                cxtab[k] = XEntry{ 2 * (p - f.cxlo), table_weight(d, w) };
             } else if (e < tw + (tw >> 1) + th) {
                 const int k = e - tw - (tw >> 1);
                 axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
                 const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo;
-                ytab[k] = YEntry{ r0 * c.py.lp + ((c.py.m0 + r0 * c.py.pm) & 15), r1 * c.py.lp + ((c.py.m0 + r1 * c.py.pm) & 15), w, 0 };
+                ytab[k] = YEntry{ r0 * c.py.lp + ((c.py.m0 + r0 * c.py.pm) & 15), r1 * c.py.lp + ((c.py.m0 + r1 * c.py.pm) & 15), table_weight(d, w), 0 };
             } else {
                 const int k = e - tw - (tw >> 1) - th;
                 axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
                 const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
-                cytab[k] = YEntry{ r0 * c.puv.lp + ((c.puv.m0 + r0 * c.puv.pm) & 15), r1 * c.puv.lp + ((c.puv.m0 + r1 * c.puv.pm) & 15), w, 0 };
+                cytab[k] = YEntry{ r0 * c.puv.lp + ((c.puv.m0 + r0 * c.puv.pm) & 15), r1 * c.puv.lp + ((c.puv.m0 + r1 * c.puv.pm) & 15), table_weight(d, w), 0 };
             }
         }
     };
@@ -464,8 +470,11 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
             __syncthreads();
         }
         const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-        if (j0 < d.dst_w && i0 < d.dst_h)
-            bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
+        if (j0 < d.dst_w && i0 < d.dst_h) {
+            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), ytab, cytab, ly, (T *)t.out[c.id.frame], i0, j0);
+            else if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
+            else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
+        }
         if (next >= total) break;
         tile = next;
         cur ^= 1;

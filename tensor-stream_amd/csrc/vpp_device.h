@@ -417,6 +417,31 @@ __device__ __forceinline__ uint32_t pack_u8x4(float a, float b, float c, float e
     r = __builtin_amdgcn_cvt_pk_u8_f32(c, 2u, r);
     return __builtin_amdgcn_cvt_pk_u8_f32(e, 3u, r);
 }
+// Twelve floats (one output row of a thread tile: 4 pixels x 3 channels) -> three dwords of truncated, saturated bytes.
+// v_cvt_pk_u8_f32 follows the wave's fp32 rounding mode (probed on gfx950, tools/dbg_cvt.hip: under round-toward-zero 254.9
+// -> 254, 2.5 -> 2, 300 -> 255, -3 -> 0; the switch is effective for the very next VALU instruction in both directions), so
+// with MODE.fp_round = toward zero it IS the reference's (uint8) cast of the clamped value and the twelve v_trunc_f32
+// disappear.  The two s_setreg bracket the conversions inside ONE asm statement: no float instruction of the surrounding code
+// can be scheduled between them.
+__device__ __forceinline__ void pack_u8x12_rtz(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3, float c0, float c1,
+                                               float c2, float c3, uint32_t &pa, uint32_t &pb, uint32_t &pc) {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(pa), "=&v"(pb), "=&v"(pc)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
 __device__ __forceinline__ f2 trunc2(f2 v) { return (f2){ __builtin_truncf(v.x), __builtin_truncf(v.y) }; }
 
 // Merged fp32 outputs (RGB / HSV triples): a thread owns 48 contiguous bytes of an output row, so its three
@@ -456,8 +481,11 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
         y.x = __builtin_fmaxf(0.0f, y.x);
         y.y = __builtin_fmaxf(0.0f, y.y);
         y = y * (f2){ k.y_scale, k.y_scale };
-        if constexpr (sizeof(T) == 1) { // the saturating pack below clamps (same arithmetic on the vector and the element-wise path:
-                                        // the row-tail branch then shares every value with the main path instead of recomputing it)
+        if constexpr (sizeof(T) == 1 && VEC) { // truncation and clamp are the round-toward-zero saturating pack below
+            c0[p] = y + (f2){ t0[p], t0[p] };
+            c1[p] = y + (f2){ tg[p], tg[p] };
+            c2[p] = y + (f2){ t2[p], t2[p] };
+        } else if constexpr (sizeof(T) == 1) { // element-wise flavour: the saturating pack below clamps
             c0[p] = trunc2(y + (f2){ t0[p], t0[p] });
             c1[p] = trunc2(y + (f2){ tg[p], tg[p] });
             c2[p] = trunc2(y + (f2){ t2[p], t2[p] });
@@ -529,14 +557,17 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
     } else {
         uint8_t *o = (uint8_t *)out;
         if constexpr (VEC) {
+            uint32_t pa, pb, pc;
             if constexpr (PLANAR) {
-                st1o(o, pix, pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), nt);
-                st1o(o + plane, pix, pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y), nt);
-                st1o(o + 2 * (size_t)plane, pix, pack_u8x4(c2[0].x, c2[0].y, c2[1].x, c2[1].y), nt);
+                pack_u8x12_rtz(c0[0].x, c0[0].y, c0[1].x, c0[1].y, c1[0].x, c1[0].y, c1[1].x, c1[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y, pa, pb, pc);
+                st1o(o, pix, pa, nt);
+                st1o(o + plane, pix, pb, nt);
+                st1o(o + 2 * (size_t)plane, pix, pc, nt);
             } else {
-                st1o(o, 3u * pix, pack_u8x4(c0[0].x, c1[0].x, c2[0].x, c0[0].y), nt);
-                st1o(o, 3u * pix + 4u, pack_u8x4(c1[0].y, c2[0].y, c0[1].x, c1[1].x), nt);
-                st1o(o, 3u * pix + 8u, pack_u8x4(c2[1].x, c0[1].y, c1[1].y, c2[1].y), nt);
+                pack_u8x12_rtz(c0[0].x, c1[0].x, c2[0].x, c0[0].y, c1[0].y, c2[0].y, c0[1].x, c1[1].x, c2[1].x, c0[1].y, c1[1].y, c2[1].y, pa, pb, pc);
+                st1o(o, 3u * pix, pa, nt);
+                st1o(o, 3u * pix + 4u, pb, nt);
+                st1o(o, 3u * pix + 8u, pc, nt);
             }
         } else {
             const uint32_t p0 = pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), p1 = pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y),
@@ -835,16 +866,25 @@ __device__ __forceinline__ void stage_plane_dma(uint8_t *lds, const uint8_t *a0,
     const int total = nrows * cpr;                       // chunk slots of this tile's footprint (uniform)
     const int wave0 = (int)(threadIdx.x & ~63u);
     if (lp.pm == 0) {
-        // pitch % 16 == 0 (every decoder output): all rows share one misalignment
-        const int chmax = (lp.m0 + span - 1) >> 4;
+        // pitch % 16 == 0 (every decoder output): all rows share one misalignment.  The slot -> (row, chunk) division is done
+        // once per thread; every further round advances by nthreads slots = qs rows + rs chunks (both uniform) with a
+        // conditional wrap: ~9 full-rate VALU instructions per round instead of ~20 with three quarter-rate multiplies.
+        const uint32_t chmax = (uint32_t)(lp.m0 + span - 1) >> 4;
         const uint8_t *origin = a0 - lp.m0;
+        const uint32_t qs = __umulhi((uint32_t)nthreads, magic), rs = (uint32_t)nthreads - qs * (uint32_t)cpr;
+        const uint32_t row_step = qs * (uint32_t)pitch;
+        const uint32_t off_last = (uint32_t)(nrows - 1) * (uint32_t)pitch + 16u * chmax; // idle lanes re-fetch the last valid chunk
+        const uint32_t row0 = __umulhi(threadIdx.x, magic);
+        uint32_t ch = threadIdx.x - row0 * (uint32_t)cpr, rowoff = row0 * (uint32_t)pitch;
         for (int base = 0; base + wave0 < total; base += nthreads) { // wave-uniform trip count
-            const uint32_t sl = (uint32_t)min(base + (int)threadIdx.x, total - 1);
-            const uint32_t row = __umulhi(sl, magic);
-            const uint32_t ch = min(sl - row * (uint32_t)cpr, (uint32_t)chmax);
-            const uint8_t *src = origin + ((size_t)row * (size_t)(uint32_t)pitch + 16u * ch);
+            const uint32_t off = min(rowoff + 16u * min(ch, chmax), off_last);
+            const uint8_t *src = origin + (size_t)off;
             uint8_t *dst = lds + (base + wave0) * 16; // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            ch += rs;
+            const bool wrap = ch >= (uint32_t)cpr;
+            ch -= wrap ? (uint32_t)cpr : 0u;
+            rowoff += row_step + (wrap ? (uint32_t)pitch : 0u);
         }
         return;
     }

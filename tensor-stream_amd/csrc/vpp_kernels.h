@@ -46,6 +46,7 @@ struct LaunchDesc {
     int nx, ny, rx, ry;
     const AreaQRow *qx, *qy; // non-null: dyadic AREA tables (integer box sums)
     const float *patx4, *paty4; // float weight rows zero-padded to 4 * nkx / 4 * nky entries (direct float AREA kernel)
+    const float *area_div;      // nx * ny divisors of the float AREA kernels (row = column pattern), or null: the kernel sums the weights itself
     int nkx, nky;
     float area_rcp;          // != 0: every (column, row) pattern pair has the same divisor S = sum(wx) * sum(wy); this is 1 / S
     // grid decomposition (filled by launch_fused)
@@ -78,6 +79,7 @@ struct LaunchDesc {
     int area_box_pref, area_box; // contiguous-run box kernel allowed (TSVPP_AREA_BOX) / chosen by launch_fused
     int w_dyadic;           // host: every interpolation weight of this BILINEAR / BICUBIC / AREA-up request is a multiple of 1/16
     int bil_int_pref, bil_int; // integer 2x2-tap thread tile allowed (TSVPP_BILINEAR_INT) / chosen by launch_fused
+    int area_cols_lds_pref, cols_lds_bytes; // LDS-staged column-per-lane AREA kernel allowed (TSVPP_AREA_COLS_LDS) / its dynamic LDS size (area_cols == 2)
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
@@ -114,6 +116,7 @@ size_t bicubic_int_table_bytes(int tw, int th, int rows_y, int rows_uv, int hcs_
 hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
+hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // The 2x2-tap kernel family (vpp_bilinear.hip): BILINEAR / AREA up-scale, plain or persistent.

@@ -1311,7 +1311,9 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
-            if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // the same, one output column per lane
+            if (vec && d.area_direct == 2 && d.area_cols == 2 && !d.force_gather) // one output column per lane, footprint staged in LDS
+                return launch_area_cols_lds((OutKind)OUT, d, t, (size_t)d.cols_lds_bytes, stream, info);
+            if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // the same, taps straight from global memory
                 const dim3 cblock(MAX_THREADS); // 256 threads whatever the tile height
                 if (d.area_cols_rows == 32) {
                     if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
@@ -1387,7 +1389,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     LaunchDesc d = din;
     d.rpt = 1;
     d.bicubic_int = 0;
-    d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref && !d.persist) ? 1 : 0;
+    d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref) ? 1 : 0;
     // window form (one aligned 12-byte read per source row instead of byte reads): the four columns of a thread must span <= 8
     // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form
     if (d.bil_int && d.bil_int_pref != 2 && d.xr <= 2.0f) d.bil_int = 2;
@@ -1446,9 +1448,32 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // (four times the waves) also at 9-12 taps: 1080p -> 224^2 +11 % -- and is even at 2-4 taps
     d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
     if (d.area_cols_rows != 8 && d.area_cols_rows != 32) d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
+    d.cols_lds_bytes = 0;
     if (d.area_cols) { // fixed workgroup of 256 threads; tile = 16 x (rows / 2) thread tiles = 64 columns x 32 or 8 rows
         d.tx = 16;
         d.ty = d.area_cols_rows / 2;
+        // the tile's source footprint through LDS (vpp_area_cols.hip: 8-row tiles) while two workgroups fit a CU's 160 KiB
+        // measured (profiles/r02_area_cols_lds_ab.txt): wins from 9 horizontal taps on (1080p -> 224^2 +13 %, 4K -> 384^2 +14 %), loses
+        // at 5-8 taps, where the global kernel's windows are two or three dwords (TSVPP_AREA_COLS_LDS=2 forces it)
+        const bool want_lds = d.area_cols_lds_pref == 2 || (d.area_cols_lds_pref == 1 && d.nkx >= 3);
+        for (int th = 8; want_lds && d.area_cols != 2 && th == 8; th = 0) {
+            const int span_y = span_bound(M_AREA_DOWN, 64, d.xr, d.rx), span_uv = 2 * span_bound(M_AREA_DOWN, 32, d.xr, d.rx);
+            int rows_y = span_bound(M_AREA_DOWN, th, d.yr, d.ry), rows_uv = span_bound(M_AREA_DOWN, th / 2, d.yr, d.ry);
+            const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
+            rows_y = ((rows_y * cpr_y + 63) / 64 * 64 + cpr_y - 1) / cpr_y; // a wave instruction fills 64 consecutive chunk slots
+            rows_uv = ((rows_uv * cpr_uv + 63) / 64 * 64 + cpr_uv - 1) / cpr_uv;
+            const size_t need = (size_t)16 * ((size_t)rows_y * cpr_y + (size_t)rows_uv * cpr_uv) + 64; // + slack for the dword over-read
+            const size_t fixed = (size_t)th * 64 * 4 + (size_t)(th / 2) * 32 * 8;                      // the kernel's static yt / uvt tiles
+            if (need + fixed > 64 * 1024) continue;
+            d.area_cols = 2;
+            d.area_cols_rows = th;
+            d.ty = th / 2;
+            d.cols_lds_bytes = (int)need;
+            d.lds_span_y = span_y; d.lds_rows_y = rows_y; d.lds_cpr_y = cpr_y;
+            d.lds_span_uv = span_uv; d.lds_rows_uv = rows_uv; d.lds_cpr_uv = cpr_uv;
+            d.lds_magic_y = 0xFFFFFFFFu / (uint32_t)cpr_y + 1u;
+            d.lds_magic_uv = 0xFFFFFFFFu / (uint32_t)cpr_uv + 1u;
+        }
     }
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;

@@ -46,7 +46,7 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((2560, 1440), (1920, 1080), A, "vpp_areaf_kernel<2,2"),            # 4/3: float weights, 2 x 2 taps
     ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
-    ((1920, 1080), (224, 224), A, "vpp_area_cols_kernel<3,8"),           # 8.57 x 4.82: one column per lane, 8-row tiles
+    ((1920, 1080), (224, 224), A, "vpp_area_cols_lds_kernel<3,8,1"),     # 8.57 x 4.82: one column per lane, footprint in LDS, divisor table
     ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6: one output column per lane
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
