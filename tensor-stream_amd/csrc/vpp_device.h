@@ -463,6 +463,17 @@ template <int OUT, bool VEC> __device__ __forceinline__ MergedRun merged_run(con
         r.a = min(len, (d.dst_w - (j0 - PXW * r.m)) / PXW);
         r.lds = slab + ((int)threadIdx.x - r.m) * 48;
     }
+    // uint8 triples: a thread owns 12 contiguous bytes of the row; the same exchange turns the run's three 4-byte stores at a
+    // 12-byte stride into ONE 16-byte store by three quarters of its lanes (runs whose length is a multiple of 4 lanes)
+    if constexpr (VEC && OUT == O_U8_MERGED) {
+        if (d.u8_xchg) {
+            __shared__ __attribute__((aligned(16))) uint8_t slab8[MAX_THREADS * 12];
+            const int len = min(d.tx, 64);
+            r.m = threadIdx.x & (len - 1);
+            r.a = min(len, (d.dst_w - (j0 - PXW * r.m)) / PXW);
+            r.lds = slab8 + ((int)threadIdx.x - r.m) * 12;
+        }
+    }
     return r;
 }
 
@@ -565,9 +576,24 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                 st1o(o + 2 * (size_t)plane, pix, pc, nt);
             } else {
                 pack_u8x12_rtz(c0[0].x, c1[0].x, c2[0].x, c0[0].y, c1[0].y, c2[0].y, c0[1].x, c1[1].x, c2[1].x, c0[1].y, c1[1].y, c2[1].y, pa, pb, pc);
-                st1o(o, 3u * pix, pa, nt);
-                st1o(o, 3u * pix + 4u, pb, nt);
-                st1o(o, 3u * pix + 8u, pc, nt);
+                if (run.lds && (run.a & 3) == 0) {
+                    uint32_t *w = (uint32_t *)(run.lds + 12 * run.m);
+                    w[0] = pa;
+                    w[1] = pb;
+                    w[2] = pc;
+                    __builtin_amdgcn_wave_barrier();
+                    if (4 * run.m < 3 * run.a) { // 12 a bytes = 3 a / 4 chunks of 16
+                        typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 v = *(const u32x4 *)(run.lds + 16 * run.m);
+                        *(u32x4a4 *)(o + (3u * (pix - 4u * (uint32_t)run.m) + 16u * (uint32_t)run.m)) = v; // rows start on 4-byte boundaries only
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    st1o(o, 3u * pix, pa, nt);
+                    st1o(o, 3u * pix + 4u, pb, nt);
+                    st1o(o, 3u * pix + 8u, pc, nt);
+                }
             }
         } else {
             const uint32_t p0 = pack_u8x4(c0[0].x, c0[0].y, c0[1].x, c0[1].y), p1 = pack_u8x4(c1[0].x, c1[0].y, c1[1].x, c1[1].y),
