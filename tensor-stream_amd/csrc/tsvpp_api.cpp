@@ -207,6 +207,7 @@ struct tsvpp_ctx {
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // TSVPP_AREA2
     int lds_kb = 40;                // TSVPP_LDS_KB
+    int bilinear_win = 1;           // TSVPP_BILINEAR_WIN: window form of the float 2x2-tap thread tile
     int u8_xchg = 1;                // TSVPP_U8_XCHG: 16-byte stores for uint8 merged outputs through an in-wave LDS exchange
     int area_divtab = 1;            // TSVPP_AREA_DIVTAB: host-built divisor table for the float AREA kernels
     int area_cols_lds = 1;          // TSVPP_AREA_COLS_LDS: stage the column-per-lane AREA kernel's footprint in LDS
@@ -320,6 +321,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_COLS_LDS")) ctx->area_cols_lds = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_U8_XCHG")) ctx->u8_xchg = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BILINEAR_WIN")) ctx->bilinear_win = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
@@ -361,6 +363,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.bil_int_pref = ctx->bilinear_int;
     d.area_cols_lds_pref = ctx->area_cols_lds;
     d.u8_xchg = ctx->u8_xchg;
+    d.bil_win_pref = ctx->bilinear_win;
     d.area2_pref = ctx->area2;
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;

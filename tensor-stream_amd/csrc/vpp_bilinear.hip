@@ -246,6 +246,54 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
+// Window form of the FLOAT thread tile (LaunchDesc::bil_win: any weights, horizontal ratio <= 2): the same row windows and
+// per-column selectors as the integer window tile; v_perm_b32 yields (A, 0, B, 0) and the two taps are converted by
+// v_cvt_f32_ubyte0 / v_cvt_f32_ubyte2.  The blend is bilerp2 -- the float tile's arithmetic, unchanged.
+template <int OUT>
+__device__ __forceinline__ void bilinear_winf_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const WinColumns &k,
+                                                          const YEntry *ytab, const YEntry *cytab, int ly, typename OutT<OUT>::type *out, int i0,
+                                                          int j0) {
+    float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
+    if constexpr (!kLumaOnly<OUT>) {
+        const uint4 cy = *(const uint4 *)(cytab + ly);
+        const TapWindow T = window8(lds_uv, (int)cy.x + k.cxo0), B = window8(lds_uv, (int)cy.y + k.cxo0);
+        const float wyf = __uint_as_float(cy.z);
+        const f2 wy = { wyf, wyf }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t su = k.csel[c], sv = su + 0x00010001u;
+            const uint32_t tu = __builtin_amdgcn_perm(T.hi, T.lo, su), tv = __builtin_amdgcn_perm(T.hi, T.lo, sv);
+            const uint32_t bu = __builtin_amdgcn_perm(B.hi, B.lo, su), bv = __builtin_amdgcn_perm(B.hi, B.lo, sv);
+            const f2 A = { (float)(tu & 255u), (float)(tv & 255u) }, Bq = { (float)((tu >> 16) & 255u), (float)((tv >> 16) & 255u) };
+            const f2 C = { (float)(bu & 255u), (float)(bv & 255u) }, D = { (float)((bu >> 16) & 255u), (float)((bv >> 16) & 255u) };
+            const float wxf = __uint_as_float(k.cw[c]);
+            const f2 wx = { wxf, wxf }, omx = (f2){ 1.0f, 1.0f } - wx;
+            const f2 sum = bilerp2(A, Bq, C, D, wx, omx, wy, omy);
+            Uf[c] = __builtin_truncf(sum.x);
+            Vf[c] = __builtin_truncf(sum.y);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
+        const TapWindow T = window8(lds_y, (int)ye.x + k.xo0), B = window8(lds_y, (int)ye.y + k.xo0);
+        const float wyf = __uint_as_float(ye.z);
+        const f2 wy = { wyf, wyf }, omy = (f2){ 1.0f, 1.0f } - wy;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const uint32_t t0 = __builtin_amdgcn_perm(T.hi, T.lo, k.sel[2 * p]), t1 = __builtin_amdgcn_perm(T.hi, T.lo, k.sel[2 * p + 1]);
+            const uint32_t b0 = __builtin_amdgcn_perm(B.hi, B.lo, k.sel[2 * p]), b1 = __builtin_amdgcn_perm(B.hi, B.lo, k.sel[2 * p + 1]);
+            const f2 A = { (float)(t0 & 255u), (float)(t1 & 255u) }, Bq = { (float)((t0 >> 16) & 255u), (float)((t1 >> 16) & 255u) };
+            const f2 C = { (float)(b0 & 255u), (float)(b1 & 255u) }, D = { (float)((b0 >> 16) & 255u), (float)((b1 >> 16) & 255u) };
+            const f2 wx = { __uint_as_float(k.w[2 * p]), __uint_as_float(k.w[2 * p + 1]) }, omx = (f2){ 1.0f, 1.0f } - wx;
+            const f2 sum = bilerp2(A, Bq, C, D, wx, omx, wy, omy);
+            Yf[r][2 * p] = __builtin_truncf(sum.x);
+            Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
+        }
+    }
+    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+}
+
 // table weight field: the float weight, or for the integer tiles the packed pair (16 - 16 w) | (16 w) << 16
 __device__ __forceinline__ float table_weight(const LaunchDesc &d, float w) {
     const uint32_t k16 = (uint32_t)(w * 16.0f);
@@ -342,12 +390,13 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     // thread tile = 4 columns x (2 * rpt) rows: the tile decode, the staging set-up and the table build are
     // paid once per 8 * rpt pixels
-    if (d.bil_int == 2) {
+    if (d.bil_int == 2 || d.bil_win) {
         const WinColumns k = win_columns(xtab, cxtab, lx);
         for (int rp = 0; rp < d.rpt; rp++) {
             const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
             if (i0 >= d.dst_h) break;
-            bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
+            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
+            else bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
         }
         return;
     }
@@ -472,6 +521,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
         const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
         if (j0 < d.dst_w && i0 < d.dst_h) {
             if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), ytab, cytab, ly, (T *)t.out[c.id.frame], i0, j0);
+            else if (d.bil_win) bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), ytab, cytab, ly, (T *)t.out[c.id.frame], i0, j0);
             else if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
             else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
         }

@@ -1393,6 +1393,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // window form (one aligned 12-byte read per source row instead of byte reads): the four columns of a thread must span <= 8
     // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form
     if (d.bil_int && d.bil_int_pref != 2 && d.xr <= 2.0f) d.bil_int = 2;
+    // float weights, same windows: measured +4..6 % at ratios 1.2 / 1.4 (1080p -> 1600x900, 1366x768), -2..5 % at 1.5 x 1.27 and 1.92,
+    // even below 1 (profiles/r02_bilinear_winf_ab.txt) -- used between 1 and 1.45; TSVPP_BILINEAR_WIN=2 forces it wherever it applies
+    d.bil_win = (!d.bil_int && (mode == M_BILINEAR || mode == M_AREA_UP) && d.xr <= 2.0f &&
+                 (d.bil_win_pref == 2 || (d.bil_win_pref == 1 && d.xr > 1.0f && d.xr <= 1.45f))) ? 1 : 0;
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
     if (d.nt_stores < 0) { // per-kernel default
         // fp32 outputs: every store instruction of a wave covers whole 128-byte lines (planar: 16 contiguous
