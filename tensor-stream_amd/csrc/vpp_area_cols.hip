@@ -32,7 +32,7 @@ template <int N> __device__ __forceinline__ void lds_window(const uint8_t *lds, 
 // Workgroup: TH = 32 -> 4 waves, each samples 8 luma rows and then 4 chroma rows (balanced); TH = 8 -> SIX waves: waves 0-3
 // sample one luma row pair each, waves 4-5 the four chroma rows at the same time (with four waves two of them would run the
 // chroma chains after their luma chains while the other two idle: the tile's latency is what bounds this kernel).
-template <int TH> constexpr int cols_threads() { return TH == 8 ? 384 : 256; }
+template <int TH> constexpr int cols_threads() { return TH == 8 ? 384 : (TH == 4 ? 192 : 256); }
 // DIVTAB: the divisor of every (column pattern, row pattern) comes from a host-built table (LaunchDesc::area_div, built in
 // tsvpp_api.cpp with the same fp32 products and the same summation order) instead of one more add per tap and lane.
 template <int NK, int TH, bool DIVTAB, int OUT>
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(cols_threads<TH>()) void vpp_area_cols_lds_kernel(c
     using T = typename OutT<OUT>::type;
     constexpr int TW = 64; // output tile of the workgroup: 64 columns x TH rows
     constexpr int NTHREADS = cols_threads<TH>();
-    static_assert(TH == 32 || TH == 8, "tile height");
+    static_assert(TH == 32 || TH == 8 || TH == 4, "tile height");
     __shared__ __attribute__((aligned(16))) float yt[TH][TW];
     __shared__ __attribute__((aligned(16))) f2 uvt[TH / 2][TW / 2];
     const TileId id = decode_tile(d);
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(cols_threads<TH>()) void vpp_area_cols_lds_kernel(c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA chunks have landed
     __syncthreads();
 
-    if (TH == 32 || wave < 4) { // luma: lane = column, two output rows per lane on float pairs; rows past the frame are computed on the last valid one
-        for (int rp = 0; rp < TH / 8; rp++) {
-            const int r0 = (TH / 4) * wave + 2 * rp;
+    if (TH == 32 || wave < TH / 2) { // luma: lane = column, two output rows per lane on float pairs; rows past the frame are computed on the last valid one
+        for (int rp = 0; rp < (TH == 32 ? 4 : 1); rp++) {
+            const int r0 = (TH == 32 ? 8 : 2) * wave + 2 * rp;
             const int iA = min(i_first + r0, d.dst_h - 1), iB = min(i_first + r0 + 1, d.dst_h - 1);
             const float *wyA = d.paty4 + (iA % d.ny) * 4 * d.nky, *wyB = d.paty4 + (iB % d.ny) * 4 * d.nky;
             const int yA = (int)(d.yr * (float)iA) - ylo, yB = (int)(d.yr * (float)iB) - ylo;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(cols_threads<TH>()) void vpp_area_cols_lds_kernel(c
             yt[r0 + 1][lane] = __builtin_truncf(acc.y / div.y);
         }
     }
-    if (!d.luma_only && (TH == 32 || wave >= 4)) { // chroma: lanes 0-31 / 32-63 = the 32 chroma columns of two chroma rows; (U, V) as a pair
+    if (!d.luma_only && (TH == 32 || wave >= TH / 2)) { // chroma: lanes 0-31 / 32-63 = the 32 chroma columns of two chroma rows; (U, V) as a pair
         const int cj = min(cj_first + (lane & 31), cw - 1);
         const int cxrel = 2 * (int)(d.xr * (float)cj) - cxlo;
         const float *wxrow = d.patx4 + (cj % d.nx) * 4 * NK;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(cols_threads<TH>()) void vpp_area_cols_lds_kernel(c
 #pragma unroll
         for (int k = 0; k < NK; k++) cwx[k] = *(const vf4a4 *)(wxrow + 4 * k);
         for (int q = 0; q < (TH == 32 ? 2 : 1); q++) {
-            const int cr = (TH == 32 ? 4 * wave + 2 * q : 2 * (wave - 4)) + (lane >> 5);
+            const int cr = (TH == 32 ? 4 * wave + 2 * q : 2 * (wave - TH / 2)) + (lane >> 5);
             const int ci = min(ci_first + cr, chh - 1);
             const float *wyrow = d.paty4 + (ci % d.ny) * 4 * d.nky;
             const int y0 = (int)(d.yr * (float)ci) - cylo;
@@ -210,24 +210,34 @@ static hipError_t launch_cols_lds_nt(OutKind out, const LaunchDesc &d, const Fra
 }
 
 hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
-    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block(384u);
-    if (d.nkx < 1 || d.nkx > 3 || d.area_cols_rows != 8) return hipErrorInvalidValue;
+    const bool four = d.area_cols_rows == 4;
+    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block(four ? 192u : 384u);
+    if (d.nkx < 1 || d.nkx > 3 || (d.area_cols_rows != 8 && !four)) return hipErrorInvalidValue;
     const bool divtab = d.area_div != nullptr;
     if (info) {
-        static const char *const names[2][3] = { { "vpp_area_cols_lds_kernel<1,8,0,OUT>", "vpp_area_cols_lds_kernel<2,8,0,OUT>", "vpp_area_cols_lds_kernel<3,8,0,OUT>" },
-                                                 { "vpp_area_cols_lds_kernel<1,8,1,OUT>", "vpp_area_cols_lds_kernel<2,8,1,OUT>", "vpp_area_cols_lds_kernel<3,8,1,OUT>" } };
-        info->kernel = names[divtab ? 1 : 0][d.nkx - 1];
+        static const char *const names[2][2][3] = {
+            { { "vpp_area_cols_lds_kernel<1,8,0,OUT>", "vpp_area_cols_lds_kernel<2,8,0,OUT>", "vpp_area_cols_lds_kernel<3,8,0,OUT>" },
+              { "vpp_area_cols_lds_kernel<1,8,1,OUT>", "vpp_area_cols_lds_kernel<2,8,1,OUT>", "vpp_area_cols_lds_kernel<3,8,1,OUT>" } },
+            { { "vpp_area_cols_lds_kernel<1,4,0,OUT>", "vpp_area_cols_lds_kernel<2,4,0,OUT>", "vpp_area_cols_lds_kernel<3,4,0,OUT>" },
+              { "vpp_area_cols_lds_kernel<1,4,1,OUT>", "vpp_area_cols_lds_kernel<2,4,1,OUT>", "vpp_area_cols_lds_kernel<3,4,1,OUT>" } } };
+        info->kernel = names[four ? 1 : 0][divtab ? 1 : 0][d.nkx - 1];
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         return hipSuccess;
     }
-    switch (d.nkx * 2 + (divtab ? 1 : 0)) {
+    switch ((four ? 8 : 0) + d.nkx * 2 + (divtab ? 1 : 0)) {
     case 2: return launch_cols_lds_nt<1, 8, false>(out, d, t, grid, block, lds_bytes, stream);
     case 3: return launch_cols_lds_nt<1, 8, true>(out, d, t, grid, block, lds_bytes, stream);
     case 4: return launch_cols_lds_nt<2, 8, false>(out, d, t, grid, block, lds_bytes, stream);
     case 5: return launch_cols_lds_nt<2, 8, true>(out, d, t, grid, block, lds_bytes, stream);
     case 6: return launch_cols_lds_nt<3, 8, false>(out, d, t, grid, block, lds_bytes, stream);
-    default: return launch_cols_lds_nt<3, 8, true>(out, d, t, grid, block, lds_bytes, stream);
+    case 7: return launch_cols_lds_nt<3, 8, true>(out, d, t, grid, block, lds_bytes, stream);
+    case 10: return launch_cols_lds_nt<1, 4, false>(out, d, t, grid, block, lds_bytes, stream);
+    case 11: return launch_cols_lds_nt<1, 4, true>(out, d, t, grid, block, lds_bytes, stream);
+    case 12: return launch_cols_lds_nt<2, 4, false>(out, d, t, grid, block, lds_bytes, stream);
+    case 13: return launch_cols_lds_nt<2, 4, true>(out, d, t, grid, block, lds_bytes, stream);
+    case 14: return launch_cols_lds_nt<3, 4, false>(out, d, t, grid, block, lds_bytes, stream);
+    default: return launch_cols_lds_nt<3, 4, true>(out, d, t, grid, block, lds_bytes, stream);
     }
 }
 

@@ -81,6 +81,7 @@ struct LaunchDesc {
     int bil_int_pref, bil_int; // integer 2x2-tap thread tile allowed (TSVPP_BILINEAR_INT) / chosen by launch_fused
     int bil_win_pref, bil_win;   // window form of the float 2x2-tap thread tile allowed (TSVPP_BILINEAR_WIN) / chosen by launch_fused
     int u8_xchg;                 // uint8 merged outputs: in-wave LDS exchange -> 16-byte stores (TSVPP_U8_XCHG)
+    int area_cols_rows_pref;
     int area_cols_lds_pref, cols_lds_bytes; // LDS-staged column-per-lane AREA kernel allowed (TSVPP_AREA_COLS_LDS) / its dynamic LDS size (area_cols == 2)
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes

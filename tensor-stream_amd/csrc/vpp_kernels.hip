@@ -1318,11 +1318,17 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 if (d.area_cols_rows == 32) {
                     if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
                     else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 32, OUT>", (vpp_area_cols_kernel<2, 32, OUT>), grid, cblock, 0);
-                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 3) TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
+                    else return hipErrorInvalidValue; // 13+ taps: 8-row tiles only (launch_fused)
                 } else {
                     if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 8, OUT>", (vpp_area_cols_kernel<1, 8, OUT>), grid, cblock, 0);
                     else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 8, OUT>", (vpp_area_cols_kernel<2, 8, OUT>), grid, cblock, 0);
-                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 3) TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 4) TSVPP_LAUNCH("vpp_area_cols_kernel<4, 8, OUT>", (vpp_area_cols_kernel<4, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 5) TSVPP_LAUNCH("vpp_area_cols_kernel<5, 8, OUT>", (vpp_area_cols_kernel<5, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 6) TSVPP_LAUNCH("vpp_area_cols_kernel<6, 8, OUT>", (vpp_area_cols_kernel<6, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 7) TSVPP_LAUNCH("vpp_area_cols_kernel<7, 8, OUT>", (vpp_area_cols_kernel<7, 8, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH("vpp_area_cols_kernel<8, 8, OUT>", (vpp_area_cols_kernel<8, 8, OUT>), grid, cblock, 0);
                 }
                 return info ? hipSuccess : hipGetLastError();
             }
@@ -1441,7 +1447,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.yr >= d.area_direct_min)
         d.area_direct = 1;
     else if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && d.area_direct_fmin > 0.0f && d.xr >= d.area_direct_fmin &&
-             d.yr >= d.area_direct_fmin && d.nkx >= 1 && d.nkx <= 3 && d.patx4 && d.paty4)
+             d.yr >= d.area_direct_fmin && d.nkx >= 1 && d.nkx <= 8 && d.patx4 && d.paty4)
         d.area_direct = 2; // float weights
     else
         d.area_direct = 0;
@@ -1451,7 +1457,12 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // kernel wins from 5 horizontal taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 %, 4K -> 608x342 +11 %, and with 8-row tiles
     // (four times the waves) also at 9-12 taps: 1080p -> 224^2 +11 % -- and is even at 2-4 taps
     d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
+    d.area_cols_rows_pref = d.area_cols_rows; // TSVPP_AREA_COLS_ROWS as given (4: the LDS kernel's four-row tiles)
+    // 13-32 horizontal taps (4K -> 224 x 224, 1080p -> 128 x 72 thumbnails): only the column-per-lane kernel is instantiated that wide;
+    // without it the request takes the generic path (element-wise gathers: 4K -> 224^2 ran 2.09 ms per 64 frames, 0.05 of the roofline)
+    if (d.area_direct == 2 && d.nkx > 3 && !d.area_cols) d.area_direct = 0;
     if (d.area_cols_rows != 8 && d.area_cols_rows != 32) d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
+    if (d.nkx > 3) d.area_cols_rows = 8; // measured: 32-row tiles lose 5..50 % at 13+ taps (profiles/r02_area_wide_ab.txt)
     d.cols_lds_bytes = 0;
     if (d.area_cols) { // fixed workgroup of 256 threads; tile = 16 x (rows / 2) thread tiles = 64 columns x 32 or 8 rows
         d.tx = 16;
@@ -1459,8 +1470,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         // the tile's source footprint through LDS (vpp_area_cols.hip: 8-row tiles) while two workgroups fit a CU's 160 KiB
         // measured (profiles/r02_area_cols_lds_ab.txt): wins from 9 horizontal taps on (1080p -> 224^2 +13 %, 4K -> 384^2 +14 %), loses
         // at 5-8 taps, where the global kernel's windows are two or three dwords (TSVPP_AREA_COLS_LDS=2 forces it)
-        const bool want_lds = d.area_cols_lds_pref == 2 || (d.area_cols_lds_pref == 1 && d.nkx >= 3);
-        for (int th = 8; want_lds && d.area_cols != 2 && th == 8; th = 0) {
+        const bool want_lds = d.nkx <= 3 && (d.area_cols_lds_pref == 2 || (d.area_cols_lds_pref == 1 && d.nkx >= 3));
+        for (int th = (d.area_cols_rows_pref == 4 ? 4 : 8); want_lds && d.area_cols != 2 && th > 0; th = 0) {
             const int span_y = span_bound(M_AREA_DOWN, 64, d.xr, d.rx), span_uv = 2 * span_bound(M_AREA_DOWN, 32, d.xr, d.rx);
             int rows_y = span_bound(M_AREA_DOWN, th, d.yr, d.ry), rows_uv = span_bound(M_AREA_DOWN, th / 2, d.yr, d.ry);
             const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;

@@ -1,0 +1,59 @@
+"""GPU: AREA down-scales with 9-32 horizontal taps (ratios 8.5 .. 31: 1080p -> 224 x 224, 4K -> 224 x 224, thumbnails) against the
+oracle, bit for bit: the column-per-lane kernels (vpp_area_cols_lds_kernel with the host-built divisor table up to 12 taps,
+vpp_area_cols_kernel<4..8, 8> beyond), which replaced the generic gather path (0.05 of the roofline) for these requests."""
+import numpy as np
+import pytest
+import torch
+
+from util import synth_nv12
+
+pytestmark = pytest.mark.gpu
+AREA = 3
+
+
+def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 0, 0)):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=AREA, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+    got = vpp.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=w)
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=AREA, fourcc=fourcc, planes=planes, normalization=norm, nthreads=8, width=w)
+    g = got.cpu().numpy().ravel()
+    assert g.size == ref.size
+    bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+    assert bad.size == 0, (dst, fourcc, planes, norm, crop, bad[:8], bad.size)
+
+
+@pytest.mark.parametrize("src,dst,kernel", [
+    ((1920, 1080), (224, 224), "vpp_area_cols_lds_kernel<3,8,1"),   # 8.57 x 4.82
+    ((3840, 2160), (384, 384), "vpp_area_cols_lds_kernel<3,8,1"),   # 10 x 5.6
+    ((3840, 2160), (224, 224), "vpp_area_cols_kernel<5,8"),         # 17.1 x 9.6
+    ((1920, 1080), (128, 72), "vpp_area_cols_kernel<4,8"),          # 15 x 15: integer ratio, weights all 1
+    ((3840, 2160), (240, 136), "vpp_area_cols_kernel<4,8"),         # 16 x 15.9
+    ((3840, 2160), (150, 84), "vpp_area_cols_kernel<7,8"),          # 25.6 x 25.7
+    ((1920, 1080), (96, 96), "vpp_area_cols_kernel<5,8"),           # 20 x 11.25
+    ((3840, 2160), (160, 90), "vpp_area_cols_kernel<6,8"),          # 24 x 24
+    ((3840, 2160), (128, 72), "vpp_area_cols_kernel<8,8"),          # 30 x 30
+    ((3840, 2160), (96, 54), "vpp_fused_gather_kernel"),            # 40 x 40: beyond 32 taps -> generic path
+])
+def test_wide_ratios(vpp, oracle, src, dst, kernel):
+    import tensor_stream as ts
+    p = ts.describe(ts.FrameParameters(width=dst[0], height=dst[1], resize_type=AREA, normalization=True, planes_pos=0), src[0], src[1])
+    assert p["kernel"].startswith(kernel), p
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0])
+    run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True)
+    run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False)
+
+
+def test_wide_ratios_pitch_crop_flavours(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=77, pitch=1933)          # pitch % 16 != 0: per-row misalignment of the LDS-DMA rows
+    run(vpp, oracle, y, uv, 1920, (224, 224), norm=True)
+    run(vpp, oracle, y, uv, 1920, (128, 72), planes=1)
+    run(vpp, oracle, y, uv, 1920, (150, 100), crop=(101, 53, 1801, 1003), norm=True)   # odd origin; 11.3 x 9.5
+    run(vpp, oracle, y, uv, 1920, (222, 126), planes=1)          # width 4 k + 2: row tail launch
+    for fourcc, planes, norm in [(1, 1, False), (0, 1, True), (3, 1, False), (4, 1, False), (6, 1, True)]:   # RGB24, Y800, NV12, UYVY (second pass), HSV
+        run(vpp, oracle, y, uv, 1920, (224, 224), fourcc=fourcc, planes=planes, norm=norm)
+    for val in (0, 255):
+        yy = np.full((1080, 1920), val, np.uint8)
+        uu = np.full((540, 1920), 255 - val, np.uint8)
+        run(vpp, oracle, yy, uu, 1920, (224, 224), planes=1)
+        run(vpp, oracle, yy, uu, 1920, (96, 96), norm=True)

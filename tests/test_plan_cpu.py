@@ -47,6 +47,9 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
     ((1920, 1080), (224, 224), A, "vpp_area_cols_lds_kernel<3,8,1"),     # 8.57 x 4.82: one column per lane, footprint in LDS, divisor table
+    ((3840, 2160), (224, 224), A, "vpp_area_cols_kernel<5,8"),           # 17.1 x 9.6: 18 taps (generic gathers before: 0.05 of the roofline)
+    ((3840, 2160), (128, 72), A, "vpp_area_cols_kernel<8,8"),            # 30 x 30
+    ((3840, 2160), (96, 54), A, "vpp_fused_gather_kernel"),              # 40 x 40: beyond 32 taps
     ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6: one output column per lane
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
