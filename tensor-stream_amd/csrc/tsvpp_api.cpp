@@ -216,6 +216,8 @@ struct tsvpp_ctx {
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
+    int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles
+    GeoCache *geo = nullptr;        // ... their device copies, one set per (request geometry, tile shape)
     std::mutex area_mu;
     // NV12 intermediates of the two-pass formats (UYVY / YUV444 with a resize): one grow-only slot per stream.  A slot's
     // mutex is held while BOTH passes of a call are enqueued, so calls that share a stream (typically NULL) cannot
@@ -311,6 +313,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA_POW2")) ctx->dma_pow2 = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_GEO")) ctx->geo_pref = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
@@ -369,6 +372,8 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_cols_pref = ctx->area_cols;
     d.area_cols_rows = ctx->area_cols_rows;
     d.num_cus = ctx->num_cus;
+    d.geo_pref = ctx->geo_pref;
+    d.geo_cache = ctx->geo;
 }
 
 // Integer box sums are exact (and equal to the reference's float accumulation) while 255 * sum(wx) * sum(wy) stays
@@ -580,6 +585,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     }
     tsvpp_default_coeffs(&ctx->coeffs);
     read_env_knobs(ctx);
+    ctx->geo = geo_cache_create();
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
@@ -590,6 +596,7 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
         if (e != hipSuccess) {
             for (auto &st : ctx->streams)
                 if (st.second) (void)hipStreamDestroy(st.second);
+            geo_cache_destroy(ctx->geo);
             delete ctx;
             return (int)e;
         }
@@ -613,8 +620,10 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
         if (a.second.qdev) (void)hipFree(a.second.qdev);
         if (a.second.dev4) (void)hipFree(a.second.dev4);
     }
-    for (auto &a : ctx->area_div)
-        if (a.second) (void)hipFree(a.second);
+        for (auto &a : ctx->area_div)
+            if (a.second) (void)hipFree(a.second);
+        geo_cache_destroy(ctx->geo);
+        ctx->geo = nullptr;
     }
     delete ctx;
 }
@@ -677,6 +686,28 @@ int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int
         tsvpp_ctx::ScratchSlot *slot = scratch_slot(ctx, stream);
         std::lock_guard<std::mutex> lk(slot->mu);
         sts = scratch_grow(ctx, slot, scratch_frame_bytes(pl) * (size_t)n_frames);
+        if (sts != TSVPP_OK) return sts;
+    }
+    if ((pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) && ctx->geo_pref) {
+        // geometry tables of the 2x2-tap kernel: a dry run of the launch chooses the tile shape and builds them.  They do not
+        // depend on the pitches (only their use does: multiples of 16) nor on the batch size beyond the tile shape -- a
+        // conversion that ends up with another shape builds its own set on first use.
+        LaunchDesc d;
+        const int pitch = (in_width + 255) & ~255;
+        fill_desc(ctx, pl, pitch, pitch, d);
+        d.in_aligned4 = 1;
+        d.geo_build = 1;
+        FrameTable t = {};
+        const int total = n_frames > 0 ? n_frames : 1;
+        // the launch groups tsvpp_convert_batch forms: full groups of TSVPP_MAX_BATCH frames, then the remainder
+        const int groups[2] = { total >= TSVPP_MAX_BATCH ? TSVPP_MAX_BATCH : 0, total % TSVPP_MAX_BATCH };
+        for (int cnt : groups) {
+            if (cnt == 0) continue;
+            d.n_frames = cnt;
+            LaunchInfo info = {};
+            hipError_t e = launch_fused(pl.mode, pl.out, true, d, t, (hipStream_t)stream, &info);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     return sts;
 }
@@ -913,9 +944,9 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
     for (const char *c = info.kernel; *c && kn + 1 < sizeof(kname); c++)
         if (*c != ' ') kname[kn++] = *c;
     kname[kn] = 0;
-    std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d tail=%d%s",
+    std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d tail=%d geo=%d%s",
                   mode_names[pl.mode], out_names[pl.out], pl.src_w, pl.src_h, pl.dst_w, pl.dst_h, kname, info.tx, info.ty, info.rpt, info.dma,
-                  info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames, info.tail,
+                  info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames, info.tail, info.geo,
                   two_pass ? (pl.fourcc == TSVPP_UYVY ? " pass2=fmt_uyvy" : " pass2=fmt_yuv444") : "");
     return TSVPP_OK;
 }

@@ -6,6 +6,12 @@
 // whatever the output type (LDS-bound) against 154 us for the float tile (profiles/r02_bilinear_int_ab.txt).
 #include "vpp_device.h"
 
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #pragma clang fp contract(off)
 
 namespace tsvpp {
@@ -213,14 +219,32 @@ __device__ __forceinline__ WinColumns win_columns(const XEntry *xtab, const XEnt
     k.cw[0] = c.y; k.cw[1] = c.w;
     return k;
 }
+// The rows of one thread tile: LDS byte offsets of the top / bottom tap rows (without the column part, which is WinColumns::xo0 /
+// cxo0) and the row weights (packed integers or float bits), for the two luma rows and the one chroma row.  Filled from the
+// workgroup's LDS coordinate tables (vpp_bilinear_kernel) or from the host-built geometry tables (vpp_bilinear_geo_kernel).
+struct RowPairGeo {
+    int top[PXH], bot[PXH];
+    uint32_t wy[PXH];
+    int ctop, cbot;
+    uint32_t cwy;
+};
+__device__ __forceinline__ RowPairGeo rows_from_lds(const YEntry *ytab, const YEntry *cytab, int ly) {
+    RowPairGeo g;
+    const uint4 cy = *(const uint4 *)(cytab + ly);
+    g.ctop = (int)cy.x; g.cbot = (int)cy.y; g.cwy = cy.z;
+#pragma unroll
+    for (int r = 0; r < PXH; r++) {
+        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
+        g.top[r] = (int)ye.x; g.bot[r] = (int)ye.y; g.wy[r] = ye.z;
+    }
+    return g;
+}
 template <int OUT>
 __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const WinColumns &k,
-                                                         const YEntry *ytab, const YEntry *cytab, int ly, typename OutT<OUT>::type *out, int i0,
-                                                         int j0) {
+                                                         const RowPairGeo &g, typename OutT<OUT>::type *out, int i0, int j0) {
     float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
     if constexpr (!kLumaOnly<OUT>) {
-        const uint4 cy = *(const uint4 *)(cytab + ly);
-        const TapWindow T = window8(lds_uv, (int)cy.x + k.cxo0), B = window8(lds_uv, (int)cy.y + k.cxo0);
+        const TapWindow T = window8(lds_uv, g.ctop + k.cxo0), B = window8(lds_uv, g.cbot + k.cxo0);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const uint32_t su = k.csel[c], sv = su + 0x00010001u;
@@ -228,19 +252,18 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
             const uint32_t tv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, sv), k.cw[c], 0u, false);
             const uint32_t bu = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, su), k.cw[c], 0u, false);
             const uint32_t bv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, sv), k.cw[c], 0u, false);
-            Uf[c] = (float)((vpair(tu, bu, cy.z) >> 8) & 255u);
-            Vf[c] = (float)((vpair(tv, bv, cy.z) >> 8) & 255u);
+            Uf[c] = (float)((vpair(tu, bu, g.cwy) >> 8) & 255u);
+            Vf[c] = (float)((vpair(tv, bv, g.cwy) >> 8) & 255u);
         }
     }
 #pragma unroll
     for (int r = 0; r < PXH; r++) {
-        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
-        const TapWindow T = window8(lds_y, (int)ye.x + k.xo0), B = window8(lds_y, (int)ye.y + k.xo0);
+        const TapWindow T = window8(lds_y, g.top[r] + k.xo0), B = window8(lds_y, g.bot[r] + k.xo0);
 #pragma unroll
         for (int c = 0; c < PXW; c++) {
             const uint32_t tt = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, k.sel[c]), k.w[c], 0u, false);
             const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, k.sel[c]), k.w[c], 0u, false);
-            Yf[r][c] = (float)((vpair(tt, bb, ye.z) >> 8) & 255u);
+            Yf[r][c] = (float)((vpair(tt, bb, g.wy[r]) >> 8) & 255u);
         }
     }
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
@@ -251,13 +274,11 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
 // v_cvt_f32_ubyte0 / v_cvt_f32_ubyte2.  The blend is bilerp2 -- the float tile's arithmetic, unchanged.
 template <int OUT>
 __device__ __forceinline__ void bilinear_winf_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const WinColumns &k,
-                                                          const YEntry *ytab, const YEntry *cytab, int ly, typename OutT<OUT>::type *out, int i0,
-                                                          int j0) {
+                                                          const RowPairGeo &g, typename OutT<OUT>::type *out, int i0, int j0) {
     float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
     if constexpr (!kLumaOnly<OUT>) {
-        const uint4 cy = *(const uint4 *)(cytab + ly);
-        const TapWindow T = window8(lds_uv, (int)cy.x + k.cxo0), B = window8(lds_uv, (int)cy.y + k.cxo0);
-        const float wyf = __uint_as_float(cy.z);
+        const TapWindow T = window8(lds_uv, g.ctop + k.cxo0), B = window8(lds_uv, g.cbot + k.cxo0);
+        const float wyf = __uint_as_float(g.cwy);
         const f2 wy = { wyf, wyf }, omy = (f2){ 1.0f, 1.0f } - wy;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -275,9 +296,8 @@ __device__ __forceinline__ void bilinear_winf_thread_tile(const LaunchDesc &d, c
     }
 #pragma unroll
     for (int r = 0; r < PXH; r++) {
-        const uint4 ye = *(const uint4 *)(ytab + ly * PXH + r);
-        const TapWindow T = window8(lds_y, (int)ye.x + k.xo0), B = window8(lds_y, (int)ye.y + k.xo0);
-        const float wyf = __uint_as_float(ye.z);
+        const TapWindow T = window8(lds_y, g.top[r] + k.xo0), B = window8(lds_y, g.bot[r] + k.xo0);
+        const float wyf = __uint_as_float(g.wy[r]);
         const f2 wy = { wyf, wyf }, omy = (f2){ 1.0f, 1.0f } - wy;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -395,8 +415,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
         for (int rp = 0; rp < d.rpt; rp++) {
             const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
             if (i0 >= d.dst_h) break;
-            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
-            else bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, ytab, cytab, lyr, (T *)t.out[id.frame], i0, j0);
+            const RowPairGeo g = rows_from_lds(ytab, cytab, lyr);
+            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, g, (T *)t.out[id.frame], i0, j0);
+            else bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, g, (T *)t.out[id.frame], i0, j0);
         }
         return;
     }
@@ -405,6 +426,109 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
         if (i0 >= d.dst_h) break;
         if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
         else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, lyr, (T *)t.out[id.frame], i0, j0);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Geometry-table variant of the 2x2-tap kernel (window tiles, LDS-DMA staging, pitches that are multiples of 16).
+// In vpp_bilinear_kernel more than half of a wave's VALU instructions are NOT blends or colour arithmetic: they are the tile's
+// footprint (eight coordinate evaluations on wave-uniform values -- gfx950 has no scalar float unit), the workgroup's
+// coordinate tables (one evaluation per lane, written to LDS, a barrier, read back, turned into selectors) -- about 300 of the 645
+// VALU instructions a wave of the uint8 1080p -> 720p launch executes, and that launch keeps the VALUs 76 % busy
+// (profiles/r02_u8_window_pmc.txt).  None of it depends on the frame: for a given request and tile shape it is the same for every
+// tile column / tile row / output column / output row.  The host therefore evaluates the coordinate functions ONCE per
+// (request, tile shape) -- the same __host__ __device__ functions of vpp_axis.h, IEEE operation for IEEE operation -- and
+// keeps the results in device memory (GeoCache, owned by the context; built by tsvpp_prepare_batch or on first use):
+//   geo_tx[tile column] = { xlo, xhi, cxlo, cxhi }   geo_ty[tile row] = { ylo, yhi, cylo, cyhi }         -- scalar loads
+//   geo_col[output column quad] : first tap column, v_perm selectors and weights of the 4 luma / 2 chroma columns   (64 B)
+//   geo_row[output row pair]    : LDS row offsets (row * LDS pitch) and weights of the 2 luma rows / 1 chroma row  (48 B)
+// A thread loads its column record and its first row-pair record before the staging (the latency hides behind the LDS-DMA),
+// no coordinate table is built in LDS and the kernel is the same for BILINEAR and the AREA up-scale.
+struct RowRec { uint4 a, b, c; };
+__device__ __forceinline__ RowRec load_row_rec(const uint4 *geo_row, int pair) {
+    const uint4 *g = geo_row + 3 * pair;
+    return RowRec{ g[0], g[1], g[2] };
+}
+__device__ __forceinline__ RowPairGeo rows_from_rec(const RowRec &r) {
+    RowPairGeo g;
+    g.top[0] = (int)r.a.x; g.bot[0] = (int)r.a.y; g.wy[0] = r.a.z; g.ctop = (int)r.a.w;
+    g.top[1] = (int)r.b.x; g.bot[1] = (int)r.b.y; g.wy[1] = r.b.z; g.cbot = (int)r.b.w;
+    g.cwy = r.c.x;
+    return g;
+}
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_geo_kernel(const LaunchDesc d, const FrameTable t) {
+    using T = typename OutT<OUT>::type;
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int nthreads = d.tx * d.ty;
+    const int4 gx = d.geo_tx[id.tx], gy = d.geo_ty[id.ty]; // uniform addresses: scalar loads
+    const int xlo = gx.x, xhi = gx.y, cxlo = gx.z, cxhi = gx.w, ylo = gy.x, yhi = gy.y, cylo = gy.z, cyhi = gy.w;
+    const int j_first = id.tx * d.tx * PXW, i_first = id.ty * d.ty * PXH * d.rpt;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = j_first + lx * PXW, lyr0 = ly * d.rpt;
+    const int nquads = (d.dst_w + 3) >> 2, npairs = d.dst_h >> 1;
+    const uint4 *gc = d.geo_col + 4 * min(j0 >> 2, nquads - 1);
+    const uint4 c0 = gc[0], c1 = gc[1], c2 = gc[2], c3 = gc[3];
+    // row-pair records of this thread's first two row pairs (rpt <= 2 for every default shape: both are in flight during the staging)
+    const int pair0 = (i_first >> 1) + lyr0;
+    RowRec ra = load_row_rec(d.geo_row, min(pair0, npairs - 1)), rb = load_row_rec(d.geo_row, min(pair0 + 1, npairs - 1));
+
+    uint8_t *lds_y = lds_raw;
+    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
+    const int cw = d.src_w >> 1;
+    const uint8_t *ay, *auv;
+    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, ylo, xlo, d.lds_cpr_y, ay);
+    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, cylo, 2 * cxlo, d.lds_cpr_uv, auv);
+    const int ny = min(yhi - ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(cyhi - cylo + 1, d.lds_rows_uv);
+    stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, min(xhi - xlo + 1, d.lds_span_y), d.lds_magic_y, nthreads);
+    stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (cxhi - cxlo + 1), d.lds_span_uv), d.lds_magic_uv, nthreads);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA chunks have landed
+    __syncthreads();
+    // replicate the last column / chroma pair one step past the plane (tiles on the right edge only); pitch % 16 == 0: every
+    // row has the misalignment m0
+    const bool edge_y = (xhi == d.src_w - 1), edge_uv = (cxhi == cw - 1);
+    if (edge_y || edge_uv) {
+        if (edge_y)
+            for (int r = threadIdx.x; r < ny; r += nthreads) {
+                uint8_t *q = lds_y + r * py.lp + py.m0 + (d.src_w - xlo);
+                q[0] = q[-1];
+            }
+        if (edge_uv)
+            for (int r = threadIdx.x; r < nuv; r += nthreads) {
+                uint8_t *q = lds_uv + r * puv.lp + puv.m0 + 2 * (cw - cxlo);
+                q[0] = q[-2];
+                q[1] = q[-1];
+            }
+        __syncthreads();
+    }
+    if (j0 >= d.dst_w) return;
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
+    // column record -> WinColumns; the tile's origin (uniform) folds into the column offsets: LDS address of source (row, col) =
+    // (row - ylo) * lp + m0 + (col - xlo), and geo_row carries row * lp
+    WinColumns k;
+    k.xo0 = (int)c0.x + (py.m0 - xlo - ylo * py.lp);
+    k.cxo0 = (int)c0.y + (puv.m0 - 2 * cxlo - cylo * puv.lp);
+    k.sel[0] = c0.z; k.sel[1] = c0.w; k.sel[2] = c1.x; k.sel[3] = c1.y;
+    k.w[0] = c1.z; k.w[1] = c1.w; k.w[2] = c2.x; k.w[3] = c2.y;
+    k.csel[0] = 0x0c020c00u;
+    k.csel[1] = c2.z;
+    k.cw[0] = c2.w; k.cw[1] = c3.x;
+    for (int rp = 0; rp < d.rpt; rp += 2) {
+        const int i0 = i_first + (lyr0 + rp) * PXH;
+        if (i0 >= d.dst_h) break;
+        const bool second = rp + 1 < d.rpt && i0 + PXH < d.dst_h;
+        if (d.bil_int == 2) {
+            bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, rows_from_rec(ra), (T *)t.out[id.frame], i0, j0);
+            if (second) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, rows_from_rec(rb), (T *)t.out[id.frame], i0 + PXH, j0);
+        } else {
+            bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, rows_from_rec(ra), (T *)t.out[id.frame], i0, j0);
+            if (second) bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, rows_from_rec(rb), (T *)t.out[id.frame], i0 + PXH, j0);
+        }
+        if (rp + 2 < d.rpt) { // TSVPP_RPT > 2 only
+            ra = load_row_rec(d.geo_row, min((i0 >> 1) + 2, npairs - 1));
+            rb = load_row_rec(d.geo_row, min((i0 >> 1) + 3, npairs - 1));
+        }
     }
 }
 
@@ -520,8 +644,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
         }
         const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
         if (j0 < d.dst_w && i0 < d.dst_h) {
-            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), ytab, cytab, ly, (T *)t.out[c.id.frame], i0, j0);
-            else if (d.bil_win) bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), ytab, cytab, ly, (T *)t.out[c.id.frame], i0, j0);
+            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), rows_from_lds(ytab, cytab, ly), (T *)t.out[c.id.frame], i0, j0);
+            else if (d.bil_win) bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), rows_from_lds(ytab, cytab, ly), (T *)t.out[c.id.frame], i0, j0);
             else if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
             else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
         }
@@ -529,6 +653,180 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(co
         tile = next;
         cur ^= 1;
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Host side of the geometry tables.
+struct GeoHost {
+    std::vector<int4> tx, ty;
+    std::vector<uint4> col, row;
+};
+// Evaluates the coordinate functions for one (request, tile shape).  false: some thread tile's taps do not fit the 8-byte
+// windows (cannot happen for ratios <= 2; checked, not assumed) -- the caller keeps vpp_bilinear_kernel.
+static bool geo_tables_host(bool areaup, const LaunchDesc &d, GeoHost &g) {
+    auto axis = [&](int idx, float ratio, int limit, int &p, float &w) {
+        if (areaup) areaup_axis(idx, ratio, p, w);
+        else bilinear_axis(idx, ratio, limit, p, w);
+    };
+    auto weight = [&](float w) -> uint32_t { // table_weight()
+        if (d.bil_int) {
+            const uint32_t k16 = (uint32_t)(w * 16.0f);
+            return (16u - k16) | (k16 << 16);
+        }
+        uint32_t u;
+        memcpy(&u, &w, 4);
+        return u;
+    };
+    const int tw = d.tx * PXW, th = d.ty * PXH * d.rpt;
+    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
+    const int lp_y = 16 * d.lds_cpr_y, lp_uv = 16 * d.lds_cpr_uv;
+    // tile footprints: tile_footprint<M_BILINEAR / M_AREA_UP>, axis_span
+    auto span = [&](int o0, int o1, float ratio, int limit, int hi_max, int &lo, int &hi) {
+        float w;
+        axis(o0, ratio, limit, lo, w);
+        axis(o1, ratio, limit, hi, w);
+        hi += 1;
+        lo = std::max(lo, 0);
+        hi = std::min(hi, hi_max);
+    };
+    g.tx.resize((size_t)d.tiles_x);
+    for (int c = 0; c < d.tiles_x; c++) {
+        const int j_first = c * tw, j_last = std::min(j_first + tw, d.dst_w) - 1;
+        int4 v;
+        span(j_first, j_last, d.xr, d.src_w, d.src_w - 1, v.x, v.y);
+        span(j_first >> 1, j_last >> 1, d.xr, d.src_w, cw - 1, v.z, v.w);
+        g.tx[(size_t)c] = v;
+    }
+    g.ty.resize((size_t)d.tiles_y);
+    for (int r = 0; r < d.tiles_y; r++) {
+        const int i_first = r * th, i_last = std::min(i_first + th, d.dst_h) - 1;
+        int4 v;
+        span(i_first, i_last, d.yr, d.src_h, d.src_h - 1, v.x, v.y);
+        span(i_first >> 1, i_last >> 1, d.yr, d.src_h, chh - 1, v.z, v.w);
+        g.ty[(size_t)r] = v;
+    }
+    // column records: win_columns() of every output column quad, first tap as an absolute source column
+    const int nquads = (d.dst_w + 3) >> 2;
+    g.col.assign((size_t)nquads * 4, make_uint4(0, 0, 0, 0));
+    for (int q = 0; q < nquads; q++) {
+        int px[PXW], cp[2];
+        float wx[PXW], cwx[2];
+        for (int i = 0; i < PXW; i++) axis(std::min(4 * q + i, d.dst_w - 1), d.xr, d.src_w, px[i], wx[i]);
+        for (int c = 0; c < 2; c++) axis(std::min(2 * q + c, (d.dst_w >> 1) - 1), d.xr, d.src_w, cp[c], cwx[c]);
+        uint32_t sel[PXW];
+        for (int i = 0; i < PXW; i++) {
+            const int rel = px[i] - px[0];
+            if (rel < 0 || rel > 6) return false; // taps rel, rel + 1 of an 8-byte window
+            sel[i] = (uint32_t)rel * 0x00010001u + 0x0c010c00u;
+        }
+        const int crel = 2 * (cp[1] - cp[0]);
+        if (crel < 0 || crel > 4) return false; // bytes crel .. crel + 3 (U V U V) of an 8-byte window
+        uint4 *o = &g.col[(size_t)q * 4];
+        o[0] = make_uint4((uint32_t)px[0], (uint32_t)(2 * cp[0]), sel[0], sel[1]);
+        o[1] = make_uint4(sel[2], sel[3], weight(wx[0]), weight(wx[1]));
+        o[2] = make_uint4(weight(wx[2]), weight(wx[3]), (uint32_t)crel * 0x00010001u + 0x0c020c00u, weight(cwx[0]));
+        o[3] = make_uint4(weight(cwx[1]), 0u, 0u, 0u);
+    }
+    // row-pair records: the YEntry pairs of vpp_bilinear_kernel with absolute rows (times the LDS row pitch)
+    const int npairs = d.dst_h >> 1;
+    g.row.assign((size_t)npairs * 3, make_uint4(0, 0, 0, 0));
+    for (int ip = 0; ip < npairs; ip++) {
+        int p[PXH], b[PXH], cpv, cb;
+        float w[PXH], cwv;
+        for (int r = 0; r < PXH; r++) {
+            axis(2 * ip + r, d.yr, d.src_h, p[r], w[r]);
+            b[r] = (p[r] + 1 >= d.src_h) ? p[r] : p[r] + 1; // y + 1 >= height -> same row
+        }
+        axis(ip, d.yr, d.src_h, cpv, cwv);
+        cb = (cpv + 1 >= chh) ? cpv : cpv + 1;
+        uint4 *o = &g.row[(size_t)ip * 3];
+        o[0] = make_uint4((uint32_t)(p[0] * lp_y), (uint32_t)(b[0] * lp_y), weight(w[0]), (uint32_t)(cpv * lp_uv));
+        o[1] = make_uint4((uint32_t)(p[1] * lp_y), (uint32_t)(b[1] * lp_y), weight(w[1]), (uint32_t)(cb * lp_uv));
+        o[2] = make_uint4(weight(cwv), 0u, 0u, 0u);
+    }
+    return true;
+}
+
+struct GeoKey {
+    int v[16];
+    bool operator<(const GeoKey &o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+struct GeoEntry {
+    uint8_t *dev = nullptr; // one allocation: tx | ty | col | row (null: the request is not eligible)
+    size_t off_ty = 0, off_col = 0, off_row = 0;
+};
+struct GeoCache {
+    std::mutex mu;
+    std::map<GeoKey, GeoEntry> map;
+};
+GeoCache *geo_cache_create() { return new GeoCache(); }
+void geo_cache_destroy(GeoCache *c) {
+    if (!c) return;
+    for (auto &e : c->map)
+        if (e.second.dev) (void)hipFree(e.second.dev);
+    delete c;
+}
+constexpr size_t kGeoMaxEntries = 256; // beyond that (a context that has seen 256 geometries) new ones keep vpp_bilinear_kernel
+
+// The tables of this launch (d: shape and LDS layout already chosen), built and uploaded on first use.  Never allocates while
+// the stream is being captured into a graph (the launch then keeps vpp_bilinear_kernel; tsvpp_prepare_batch avoids that).
+static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStream_t stream, bool may_build, LaunchDesc &out) {
+    GeoKey key;
+    memset(&key, 0, sizeof(key));
+    uint32_t xb, yb;
+    memcpy(&xb, &d.xr, 4);
+    memcpy(&yb, &d.yr, 4);
+    const int kv[16] = { areaup ? 1 : 0, d.src_w, d.src_h, d.dst_w, d.dst_h, (int)xb, (int)yb, d.tx, d.ty, d.rpt, d.bil_int, d.lds_cpr_y, d.lds_cpr_uv,
+                         d.tiles_x, d.tiles_y, 0 };
+    memcpy(key.v, kv, sizeof(kv));
+    std::lock_guard<std::mutex> lk(cache->mu);
+    auto it = cache->map.find(key);
+    if (it == cache->map.end()) {
+        if (!may_build || cache->map.size() >= kGeoMaxEntries) return false;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+        GeoHost g;
+        GeoEntry e;
+        if (geo_tables_host(areaup, d, g)) {
+            auto up16 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+            const size_t b_tx = g.tx.size() * sizeof(int4), b_ty = g.ty.size() * sizeof(int4), b_col = g.col.size() * sizeof(uint4),
+                         b_row = g.row.size() * sizeof(uint4);
+            e.off_ty = up16(b_tx);
+            e.off_col = e.off_ty + up16(b_ty);
+            e.off_row = e.off_col + up16(b_col);
+            const size_t total = e.off_row + up16(b_row);
+            std::vector<uint8_t> host(total, 0);
+            memcpy(host.data(), g.tx.data(), b_tx);
+            memcpy(host.data() + e.off_ty, g.ty.data(), b_ty);
+            memcpy(host.data() + e.off_col, g.col.data(), b_col);
+            memcpy(host.data() + e.off_row, g.row.data(), b_row);
+            if (hipMalloc((void **)&e.dev, total) != hipSuccess) return false;
+            if (hipMemcpy(e.dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(e.dev);
+                return false;
+            }
+        }
+        it = cache->map.emplace(key, e).first;
+    }
+    const GeoEntry &e = it->second;
+    if (!e.dev) return false;
+    out.geo_tx = (const int4 *)e.dev;
+    out.geo_ty = (const int4 *)(e.dev + e.off_ty);
+    out.geo_col = (const uint4 *)(e.dev + e.off_col);
+    out.geo_row = (const uint4 *)(e.dev + e.off_row);
+    return true;
+}
+
+static hipError_t launch_bilinear_geo(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    switch (out) {
+#define TSVPP_GEO(O)                                                                               \
+    case O: hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O>), grid, block, lds, stream, d, t); break;
+        TSVPP_GEO(O_U8_PLANAR) TSVPP_GEO(O_U8_MERGED) TSVPP_GEO(O_F32_PLANAR) TSVPP_GEO(O_F32_MERGED) TSVPP_GEO(O_NV12_U8)
+        TSVPP_GEO(O_NV12_F32) TSVPP_GEO(O_Y800_U8) TSVPP_GEO(O_Y800_F32) TSVPP_GEO(O_HSV_F32)
+#undef TSVPP_GEO
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 template <bool AREAUP>
@@ -547,16 +845,34 @@ static hipError_t launch_bilinear_a(OutKind out, bool persistent, const LaunchDe
     return hipGetLastError();
 }
 
-hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &d, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
+hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &din, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
                            hipStream_t stream, LaunchInfo *info) {
+    LaunchDesc d = din;
     dim3 grid(grid_x), block((unsigned)(d.tx * d.ty));
+    // geometry tables: window tiles on LDS-DMA staging with pitches that are multiples of 16 (every row then has one
+    // misalignment); the coordinate tables of vpp_bilinear_kernel no longer occupy LDS
+    d.geo = 0;
+    const bool geo_ok = !persistent && d.geo_pref && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
+    if (geo_ok) {
+        if (d.geo_cache) d.geo = geo_lookup(d.geo_cache, areaup, d, stream, !info || d.geo_build, d) ? 1 : 0;
+        else if (info) { // tsvpp_describe: no device -- eligibility only
+            GeoHost g;
+            d.geo = geo_tables_host(areaup, d, g) ? 1 : 0;
+        }
+    }
+    if (d.geo) { // no coordinate tables in LDS
+        const size_t cols = (size_t)d.tx * PXW, rows = (size_t)d.ty * PXH * d.rpt;
+        lds_bytes -= (cols + cols / 2) * sizeof(XEntry) + (rows + rows / 2) * sizeof(YEntry);
+    }
     if (info) {
         info->kernel = persistent ? (areaup ? "vpp_bilinear_persistent_kernel<areaup,OUT>" : "vpp_bilinear_persistent_kernel<bilinear,OUT>")
                                   : (areaup ? "vpp_bilinear_kernel<areaup,OUT>" : "vpp_bilinear_kernel<bilinear,OUT>");
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
+        info->geo = d.geo;
         return hipSuccess;
     }
+    if (d.geo) return launch_bilinear_geo(out, d, t, grid, block, lds_bytes, stream);
     return areaup ? launch_bilinear_a<true>(out, persistent, d, t, grid, block, lds_bytes, stream)
                   : launch_bilinear_a<false>(out, persistent, d, t, grid, block, lds_bytes, stream);
 }

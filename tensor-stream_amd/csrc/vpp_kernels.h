@@ -32,6 +32,8 @@ struct AreaQRow {
     int32_t pad;
 };
 
+struct GeoCache; // host side: device-resident geometry tables of the 2x2-tap kernel (vpp_bilinear.hip)
+
 struct LaunchDesc {
     // logical source = the crop box if crop is active, else the whole frame; the frame
     // pointers in FrameTable are already advanced to its top-left corner
@@ -92,7 +94,19 @@ struct LaunchDesc {
     int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled
     int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
+    // Host-built geometry tables of the 2x2-tap kernel's window tiles (vpp_bilinear.hip, "geometry tables"): tile footprints
+    // (scalar loads), one record per output column quad and per output row pair.  geo_pref: allowed (TSVPP_GEO); geo: chosen
+    // by launch_bilinear; geo_build: a dry run (info != nullptr) still builds / uploads the tables (tsvpp_prepare_batch);
+    // geo_cache: the owning context's cache (host pointer, never dereferenced on the device; null in tsvpp_describe).
+    const int4 *geo_tx, *geo_ty;
+    const uint4 *geo_col, *geo_row;
+    int geo_pref, geo, geo_build;
+    GeoCache *geo_cache;
 };
+
+// Device-resident geometry tables, one set per (request geometry, tile shape); owned by a context, freed with it.
+GeoCache *geo_cache_create();
+void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has selected the device
 
 // Output flavour: element type x layout.
 // O_NV12_*: the resized NV12 itself (Y plane then interleaved UV plane, tight) -- FourCC NV12 of the
@@ -106,6 +120,7 @@ struct LaunchInfo {
     const char *kernel;
     int tx, ty, rpt, dma, staged, lds_bytes, grid, tiles_x, tiles_y;
     int tail; // a second, element-wise launch covers the two-column row tail (dst_w = 4 k + 2)
+    int geo;  // the 2x2-tap kernel reads host-built geometry tables instead of computing coordinates
 };
 
 // Launches the fused crop+resize+colour kernel.  `vec` selects the 16-byte/4-byte vector

@@ -106,8 +106,9 @@ class VideoProcessor:
         return w.value, h.value
 
     def prepare(self, params, in_w, in_h, n_frames=0, stream=None):
-        """Pre-builds what the request needs (AREA tables; with n_frames > 0 also the UYVY / YUV444 scratch of `stream`,
-        default torch's current stream) so that later conversions allocate nothing -- e.g. before graph capture."""
+        """Pre-builds what the request needs (AREA tables, the geometry tables of the 2x2-tap kernel for a batch of `n_frames`;
+        with n_frames > 0 also the UYVY / YUV444 scratch of `stream`, default torch's current stream) so that later
+        conversions allocate nothing -- e.g. before graph capture."""
         p = params.parameters if isinstance(params, FrameParameters) else params
         if n_frames and stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -1,0 +1,128 @@
+"""GPU: the geometry-table variant of the 2x2-tap kernel (vpp_bilinear_geo_kernel: host-built footprints, column and row-pair
+records) against the oracle, bit for bit -- single frames and 64-frame batches (different tile shapes), misaligned crop
+origins, right / bottom edges, the two-column row tail, taller thread tiles, graph capture after prepare()."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import synth_nv12
+
+pytestmark = pytest.mark.gpu
+BILINEAR, AREA = 1, 3
+
+
+def params(dst, rt=BILINEAR, fourcc=2, planes=0, norm=False, crop=(0, 0, 0, 0)):
+    import tensor_stream as ts
+    return ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+
+
+def check(v, oracle, y, uv, w, dst, n=1, geo=1, **kw):
+    from tensor_stream import vpp as V
+    fp = params(dst, **kw)
+    h = y.shape[0]
+    crop = kw.get("crop", (0, 0, 0, 0))
+    # the request takes the geometry tables (host logic; the crop must not change the pitch)
+    assert V.describe(fp, w, h, pitch=y.shape[1], n_frames=n)["geo"] == geo, (w, h, dst, kw)
+    ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+    if n == 1:
+        got = v.Convert(ty, tuv, fp, width=w)
+    else:
+        got = v.convert_batch([ty] * n, [tuv] * n, fp, width=w)
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=kw.get("rt", BILINEAR), fourcc=kw.get("fourcc", 2), planes=kw.get("planes", 0),
+                               normalization=kw.get("norm", False), nthreads=8, width=w)
+    frames = [got] if n == 1 else [got[0], got[n // 2], got[n - 1]]
+    for g in frames:
+        g = g.cpu().numpy().ravel()
+        assert g.size == ref.size
+        bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, (dst, kw, n, bad[:8], bad.size)
+
+
+@pytest.mark.parametrize("src,dst,rt", [
+    ((1920, 1080), (1280, 720), BILINEAR),   # integer window tile (quarters): the headline
+    ((1920, 1080), (1600, 900), BILINEAR),   # float window tile (ratio 1.2)
+    ((1920, 1080), (1366, 768), BILINEAR),   # float window tile + the two-column row tail
+    ((1280, 720), (2560, 1440), BILINEAR),   # up-scale x2: clamped first column / row, repeated taps
+    ((960, 540), (1280, 720), BILINEAR),     # up-scale x4/3 (dyadic: quarters)
+    ((1280, 720), (1920, 1080), AREA),       # the AREA up-scale variant, float weights
+    ((640, 360), (1280, 720), AREA),         # ... dyadic weights
+    ((1920, 1088), (960, 544), BILINEAR),    # ratio exactly 2: the widest windows
+])
+@pytest.mark.parametrize("n", [1, 64])
+def test_geo_ratio_classes(vpp, oracle, src, dst, rt, n):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0] + n)
+    check(vpp, oracle, y, uv, src[0], dst, n=n, rt=rt, planes=0, norm=True)
+    check(vpp, oracle, y, uv, src[0], dst, n=n, rt=rt, planes=1, norm=False)
+    check(vpp, oracle, y, uv, src[0], dst, n=n, rt=rt, planes=0, norm=False)
+
+
+@pytest.mark.parametrize("fourcc,planes,norm", [(1, 1, True), (0, 1, False), (0, 1, True), (3, 1, False), (3, 1, True), (6, 1, True), (4, 1, False), (5, 1, True)])
+def test_geo_output_flavours(vpp, oracle, fourcc, planes, norm):
+    y, uv = synth_nv12(960, 528, seed=170 + fourcc)
+    check(vpp, oracle, y, uv, 960, (640, 352), fourcc=fourcc, planes=planes, norm=norm)          # 1.5: integer window tile
+    check(vpp, oracle, y, uv, 960, (768, 400), fourcc=fourcc, planes=planes, norm=norm, n=64)    # 1.25 x 1.32: float window tile
+
+
+def test_geo_crops_pitches_edges(vpp, oracle):
+    y, uv = synth_nv12(1000, 600, seed=115, pitch=1024)   # padded pitch, width not a multiple of 16
+    check(vpp, oracle, y, uv, 1000, (750, 450), norm=True)
+    check(vpp, oracle, y, uv, 1000, (500, 300), n=64)
+    check(vpp, oracle, y, uv, 1000, (400, 300), crop=(3, 5, 603, 455), norm=True)    # odd origin: U / V swapped, misaligned rows
+    check(vpp, oracle, y, uv, 1000, (322, 150), crop=(38, 6, 682, 306), planes=1)    # width 4 k + 2
+    check(vpp, oracle, y, uv, 1000, (1500, 900), planes=1, n=64, geo=0)   # 2/3: not dyadic, outside the float window tile's range
+    check(vpp, oracle, y, uv, 1000, (2000, 1200), planes=1, n=64)         # 1/2
+    check(vpp, oracle, y, uv, 1000, (1200, 300), rt=AREA, crop=(200, 100, 1000, 300), norm=True)   # mixed: up in x, AREA -> bilinear variant
+    for val in (0, 255):
+        yy = np.full((360, 640), val, np.uint8)
+        uu = np.full((180, 640), 255 - val, np.uint8)
+        check(vpp, oracle, yy, uu, 640, (480, 270), planes=1)
+        check(vpp, oracle, yy, uu, 640, (1280, 720), planes=1, n=64)
+    y, uv = synth_nv12(64, 32, seed=116)
+    for dst in [(48, 24), (128, 64), (56, 28), (32, 16)]:
+        check(vpp, oracle, y, uv, 64, dst, norm=True)
+
+
+def test_geo_tall_thread_tiles_and_knob_off(oracle):
+    """TSVPP_RPT=4 (two further row-pair records per thread) and TSVPP_GEO=0 (vpp_bilinear_kernel) give the same bits."""
+    import tensor_stream
+    y, uv = synth_nv12(1920, 1080, seed=117)
+    for env in ({"TSVPP_RPT": "4"}, {"TSVPP_RPT": "3"}, {"TSVPP_GEO": "0"}):
+        os.environ.update(env)
+        try:
+            v = tensor_stream.VideoProcessor(device=0)
+            fp = params((1280, 720))
+            got = v.convert_batch([torch.from_numpy(y).cuda()] * 64, [torch.from_numpy(uv).cuda()] * 64, fp, width=1920)
+            torch.cuda.synchronize()
+            ref, _, _ = oracle.convert(y, uv, dst=(1280, 720), resize_type=BILINEAR, fourcc=2, planes=0, normalization=False, nthreads=8, width=1920)
+            for f in (0, 63):
+                assert np.array_equal(got[f].cpu().numpy().ravel(), ref), env
+            v.Close()
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
+@pytest.mark.parametrize("prepared", [True, False])
+def test_geo_graph_capture(vpp, oracle, prepared):
+    """prepare() builds the geometry tables, so the FIRST conversion of a geometry can be captured into a graph; without
+    prepare() a capturing stream never allocates: the launch keeps vpp_bilinear_kernel (same bits)."""
+    src, dst = ((1280, 736), (1024, 576)) if prepared else ((1280, 736), (960, 552))
+    y, uv = synth_nv12(src[0], src[1], seed=118)
+    fp = params(dst, norm=True)
+    ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+    if prepared:
+        vpp.prepare(fp, src[0], src[1], n_frames=1)
+    out = vpp._alloc(fp.parameters, src[0], src[1])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        vpp.Convert(ty, tuv, fp, out=out, width=src[0])
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, dst=dst, resize_type=BILINEAR, fourcc=2, planes=0, normalization=True, nthreads=8, width=src[0])
+    assert np.array_equal(out.cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8))
