@@ -852,7 +852,14 @@ hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const Laun
     // geometry tables: window tiles on LDS-DMA staging with pitches that are multiples of 16 (every row then has one
     // misalignment); the coordinate tables of vpp_bilinear_kernel no longer occupy LDS
     d.geo = 0;
-    const bool geo_ok = !persistent && d.geo_pref && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
+    // Measured (profiles/r02_geo_ab.txt, same box): uint8 outputs on the integer window tile gain 2..5 % (1080p -> 720p planar 0.528 ->
+    // 0.554, 4K -> 1080p 0.695 -> 0.710: the kernel is VALU-bound there and a wave executes ~19 % fewer VALU instructions), but
+    // fp32 outputs LOSE 8..19 % (headline 0.742 -> 0.658): they are bound by the memory pipeline, and a thread's records are ten
+    // 16-byte loads per 8 or 16 pixels -- several times the source bytes the tile stages.  So: uint8 flavours with dyadic weights
+    // only; TSVPP_GEO=2 forces the tables wherever they apply, TSVPP_GEO=0 disables them.
+    const bool u8_out = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
+    const bool geo_want = d.geo_pref == 2 || (d.geo_pref == 1 && u8_out && d.bil_int == 2);
+    const bool geo_ok = !persistent && geo_want && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
     if (geo_ok) {
         if (d.geo_cache) d.geo = geo_lookup(d.geo_cache, areaup, d, stream, !info || d.geo_build, d) ? 1 : 0;
         else if (info) { // tsvpp_describe: no device -- eligibility only

@@ -13,6 +13,34 @@ pytestmark = pytest.mark.gpu
 BILINEAR, AREA = 1, 3
 
 
+class _Env:
+    """TSVPP_* knobs are read when a context is created / a request is described: set them for exactly that long."""
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def gvpp():
+    """A context with TSVPP_GEO=2: the geometry tables wherever they apply (the default uses them for uint8 outputs with
+    dyadic weights only, where they were measured to win)."""
+    import tensor_stream
+    with _Env(TSVPP_GEO="2"):
+        v = tensor_stream.VideoProcessor(device=0, max_consumers=2)
+    yield v
+    v.Close()
+
+
 def params(dst, rt=BILINEAR, fourcc=2, planes=0, norm=False, crop=(0, 0, 0, 0)):
     import tensor_stream as ts
     return ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
@@ -24,7 +52,8 @@ def check(v, oracle, y, uv, w, dst, n=1, geo=1, **kw):
     h = y.shape[0]
     crop = kw.get("crop", (0, 0, 0, 0))
     # the request takes the geometry tables (host logic; the crop must not change the pitch)
-    assert V.describe(fp, w, h, pitch=y.shape[1], n_frames=n)["geo"] == geo, (w, h, dst, kw)
+    with _Env(TSVPP_GEO="2"):
+        assert V.describe(fp, w, h, pitch=y.shape[1], n_frames=n)["geo"] == geo, (w, h, dst, kw)
     ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
     if n == 1:
         got = v.Convert(ty, tuv, fp, width=w)
@@ -52,7 +81,8 @@ def check(v, oracle, y, uv, w, dst, n=1, geo=1, **kw):
     ((1920, 1088), (960, 544), BILINEAR),    # ratio exactly 2: the widest windows
 ])
 @pytest.mark.parametrize("n", [1, 64])
-def test_geo_ratio_classes(vpp, oracle, src, dst, rt, n):
+def test_geo_ratio_classes(gvpp, oracle, src, dst, rt, n):
+    vpp = gvpp
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0] + n)
     check(vpp, oracle, y, uv, src[0], dst, n=n, rt=rt, planes=0, norm=True)
     check(vpp, oracle, y, uv, src[0], dst, n=n, rt=rt, planes=1, norm=False)
@@ -60,13 +90,15 @@ def test_geo_ratio_classes(vpp, oracle, src, dst, rt, n):
 
 
 @pytest.mark.parametrize("fourcc,planes,norm", [(1, 1, True), (0, 1, False), (0, 1, True), (3, 1, False), (3, 1, True), (6, 1, True), (4, 1, False), (5, 1, True)])
-def test_geo_output_flavours(vpp, oracle, fourcc, planes, norm):
+def test_geo_output_flavours(gvpp, oracle, fourcc, planes, norm):
+    vpp = gvpp
     y, uv = synth_nv12(960, 528, seed=170 + fourcc)
     check(vpp, oracle, y, uv, 960, (640, 352), fourcc=fourcc, planes=planes, norm=norm)          # 1.5: integer window tile
     check(vpp, oracle, y, uv, 960, (768, 400), fourcc=fourcc, planes=planes, norm=norm, n=64)    # 1.25 x 1.32: float window tile
 
 
-def test_geo_crops_pitches_edges(vpp, oracle):
+def test_geo_crops_pitches_edges(gvpp, oracle):
+    vpp = gvpp
     y, uv = synth_nv12(1000, 600, seed=115, pitch=1024)   # padded pitch, width not a multiple of 16
     check(vpp, oracle, y, uv, 1000, (750, 450), norm=True)
     check(vpp, oracle, y, uv, 1000, (500, 300), n=64)
@@ -89,7 +121,7 @@ def test_geo_tall_thread_tiles_and_knob_off(oracle):
     """TSVPP_RPT=4 (two further row-pair records per thread) and TSVPP_GEO=0 (vpp_bilinear_kernel) give the same bits."""
     import tensor_stream
     y, uv = synth_nv12(1920, 1080, seed=117)
-    for env in ({"TSVPP_RPT": "4"}, {"TSVPP_RPT": "3"}, {"TSVPP_GEO": "0"}):
+    for env in ({"TSVPP_RPT": "4"}, {"TSVPP_RPT": "3"}, {"TSVPP_GEO": "0"}, {}):   # {}: the default selection (uint8 + dyadic weights: tables)
         os.environ.update(env)
         try:
             v = tensor_stream.VideoProcessor(device=0)
@@ -106,7 +138,8 @@ def test_geo_tall_thread_tiles_and_knob_off(oracle):
 
 
 @pytest.mark.parametrize("prepared", [True, False])
-def test_geo_graph_capture(vpp, oracle, prepared):
+def test_geo_graph_capture(gvpp, oracle, prepared):
+    vpp = gvpp
     """prepare() builds the geometry tables, so the FIRST conversion of a geometry can be captured into a graph; without
     prepare() a capturing stream never allocates: the launch keeps vpp_bilinear_kernel (same bits)."""
     src, dst = ((1280, 736), (1024, 576)) if prepared else ((1280, 736), (960, 552))
