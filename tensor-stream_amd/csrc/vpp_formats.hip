@@ -7,6 +7,8 @@
 // no contraction; integer paths use C integer semantics exactly as the reference's <uchar> code.
 #include "vpp_kernels.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace tsvpp {
@@ -254,7 +256,180 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444(const FrameTable t,
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Row-pair kernels (the default wherever the planes allow vector loads): output rows 2r and 2r + 1 share chroma row r, so a
+// thread converts PX pixels of BOTH rows -- the vertical (-1, 9, 9, -1) filter of an odd chroma row runs once, not twice -- and
+// PX is chosen such that every store is 16 bytes per lane and contiguous across the wave (1 KiB per store instruction):
+//   UYVY   uint8: PX = 8 (8-byte luma / chroma loads)      fp32: PX = 2 (the single-row kernel above writes 32 bytes per lane in
+//   YUV444 uint8: PX = 16 (16-byte loads)                  fp32: PX = 4                two stores that interleave across lanes)
+// YUV444 needs the filtered chroma of the pair before and the two pairs after the thread's own: they come from the neighbouring
+// lanes by wave shuffles (ds_bpermute); the first / last lane of a wave reload one dword instead, and the first / last thread of a
+// ROW -- where the reference's flat indexing wraps into the previous / next row -- takes the scalar path (uyvy_chroma) per row.
+template <int NB> __device__ __forceinline__ void ld_bytes(const uint8_t *p, uint32_t *v) {
+    if constexpr (NB == 2) v[0] = *(const uint16_t *)p;
+    else if constexpr (NB == 4) v[0] = *(const uint32_t *)p;
+    else if constexpr (NB == 8) {
+        const uint2 q = *(const uint2 *)p;
+        v[0] = q.x; v[1] = q.y;
+    } else {
+        const uint4 q = *(const uint4 *)p;
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 255u; }
+// (9 (a + b) - (c + e) + 8) >> 4, clamped, on the four bytes of a dword (src/ColorConversion.cu:107-127).  Shift, clamp and
+// pack are gfx950's v_ashr_pk_u8_i32 -- through inline assembly: ROCm 7.2's clang selects that instruction by itself for
+// `min(max(x >> 4, 0), 255) | ... << 8` but assumes it zeroes the upper half of its destination, which the hardware PRESERVES
+// (measured; vpp_bicubic_int.hip has the full story).  Here the preserved half is put to use: the second instruction packs
+// bytes 0-1 under the bytes 2-3 already in place.
+__device__ __forceinline__ uint32_t vfilt4(uint32_t a, uint32_t b, uint32_t c, uint32_t e) {
+    int sum[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int in = (int)byte_of(a, k) + (int)byte_of(b, k), out = (int)byte_of(c, k) + (int)byte_of(e, k);
+        sum[k] = 9 * in - out + 8;
+    }
+    uint32_t hi;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 4" : "=v"(hi) : "v"(sum[2]), "v"(sum[3])); // upper half: whatever the register held, shifted out below
+    uint32_t r = hi << 16;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 4" : "+v"(r) : "v"(sum[0]), "v"(sum[1]));
+    return r;
+}
+// NB bytes of the 4:2:2 chroma of chroma row r (= output rows 2r, 2r + 1) at byte column col: chroma_422 on vectors
+template <int NB> __device__ __forceinline__ void chroma_rows(const Nv12View &s, int r, int col, uint32_t *v) {
+    constexpr int ND = (NB + 3) / 4;
+    const int last = (s.h >> 1) - 1;
+    const uint8_t *base = s.uv + col;
+    ld_bytes<NB>(base + (size_t)r * s.puv, v);
+    if (r & 1) { // uniform per wave
+        uint32_t b[ND], c[ND], e[ND];
+        ld_bytes<NB>(base + (size_t)min(r + 1, last) * s.puv, b);
+        ld_bytes<NB>(base + (size_t)max(r - 1, 0) * s.puv, c);
+        ld_bytes<NB>(base + (size_t)min(r + 2, last) * s.puv, e);
+#pragma unroll
+        for (int d = 0; d < ND; d++) v[d] = vfilt4(v[d], b[d], c[d], e[d]);
+    }
+}
+typedef float fvf4 __attribute__((ext_vector_type(4)));
+typedef uint32_t fvu4 __attribute__((ext_vector_type(4)));
+
+template <class T, int PX>
+__global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_uyvy_rp(const FrameTable t, const FmtGeom g) {
+    const int f = blockIdx.z, r = blockIdx.y * FMT_BY + threadIdx.y, j = (blockIdx.x * FMT_BX + threadIdx.x) * PX;
+    if (2 * r >= g.h || j >= g.w) return;
+    const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
+    constexpr int ND = (PX + 3) / 4;
+    uint32_t c[ND], yy[2][ND];
+    chroma_rows<PX>(s, r, j, c);
+    ld_bytes<PX>(s.y + (size_t)(2 * r) * s.py + j, yy[0]);
+    ld_bytes<PX>(s.y + (size_t)(2 * r + 1) * s.py + j, yy[1]);
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        T *o = (T *)t.out[f] + ((size_t)(2 * r + rr) * s.w + j) * 2;
+        if constexpr (sizeof(T) == 1) { // PX = 8: (U Y V Y) x 4 = 16 bytes; v_perm_b32 interleaves chroma (S1) and luma (S0) bytes
+            fvu4 v;
+            v.x = __builtin_amdgcn_perm(yy[rr][0], c[0], 0x05010400u);
+            v.y = __builtin_amdgcn_perm(yy[rr][0], c[0], 0x07030602u);
+            v.z = __builtin_amdgcn_perm(yy[rr][1], c[1], 0x05010400u);
+            v.w = __builtin_amdgcn_perm(yy[rr][1], c[1], 0x07030602u);
+            __builtin_nontemporal_store(v, (fvu4 *)o);
+        } else { // PX = 2: U Y V Y as four floats
+            const fvf4 v = { fin<float>((int)byte_of(c[0], 0)), fin<float>((int)byte_of(yy[rr][0], 0)), fin<float>((int)byte_of(c[0], 1)),
+                             fin<float>((int)byte_of(yy[rr][0], 1)) };
+            __builtin_nontemporal_store(v, (fvf4 *)o);
+        }
+    }
+}
+
+template <class T, int PX>
+__global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444_rp(const FrameTable t, const FmtGeom g) {
+    const int f = blockIdx.z, r = blockIdx.y * FMT_BY + threadIdx.y, lane = threadIdx.x, j = (blockIdx.x * FMT_BX + lane) * PX;
+    if (2 * r >= g.h || j >= g.w) return;
+    const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
+    constexpr int ND = PX / 4, NP = PX / 2;
+    uint32_t own[ND];
+    chroma_rows<PX>(s, r, j, own);
+    // filtered chroma of the neighbouring threads' nearest pairs: (pairs -2, -1) and (pairs NP, NP + 1)
+    uint32_t nbL = (uint32_t)__shfl_up((int)own[ND - 1], 1), nbR = (uint32_t)__shfl_down((int)own[0], 1);
+    const bool row_first = (j == 0), row_last = (j + PX >= s.w);
+    if (lane == 0 && !row_first) chroma_rows<4>(s, r, j - 4, &nbL);
+    if (lane == FMT_BX - 1 && !row_last) chroma_rows<4>(s, r, j + PX, &nbR);
+    int cu[NP + 3], cv[NP + 3]; // chroma of pairs -1 .. NP + 1
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        cu[p + 1] = (int)byte_of(own[p >> 1], 2 * (p & 1));
+        cv[p + 1] = (int)byte_of(own[p >> 1], 2 * (p & 1) + 1);
+    }
+    cu[0] = (int)byte_of(nbL, 2); cv[0] = (int)byte_of(nbL, 3);
+    cu[NP + 1] = (int)byte_of(nbR, 0); cv[NP + 1] = (int)byte_of(nbR, 1);
+    cu[NP + 2] = (int)byte_of(nbR, 2); cv[NP + 2] = (int)byte_of(nbR, 3);
+    const size_t wh = (size_t)s.w * s.h;
+    const uint32_t wh32 = (uint32_t)s.w * (uint32_t)s.h;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int i = 2 * r + rr;
+        // the reference indexes its intermediate UYVY image FLAT: at the ends of a row the neighbours are pairs of row i - 1 / i + 1
+        if (row_first) {
+            cu[0] = uyvy_chroma(s, i, -2, 0);
+            cv[0] = uyvy_chroma(s, i, -2, 1);
+        }
+        if (row_last) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                cu[NP + 1 + k] = uyvy_chroma(s, i, j + PX + 2 * k, 0);
+                cv[NP + 1 + k] = uyvy_chroma(s, i, j + PX + 2 * k, 1);
+            }
+        }
+        uint32_t yw[ND > 0 ? PX / 4 : 1];
+        ld_bytes<PX>(s.y + (size_t)i * s.py + j, yw);
+        T uo[PX], vo[PX];
+        const uint32_t row0 = (uint32_t)i * (uint32_t)s.w + (uint32_t)j;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t idx1 = row0 + 2 * p + 1;
+            const bool first = idx1 == 1u, last2 = idx1 + 3u >= wh32; // see fmt_yuv444
+            uo[2 * p] = fin<T>(cu[p + 1]);
+            vo[2 * p] = fin<T>(cv[p + 1]);
+            uo[2 * p + 1] = yuv444_odd<T>(cu[p + 1], cu[p + 2], first ? cu[p + 1] : cu[p], last2 ? cu[p + 2] : cu[p + 3]);
+            vo[2 * p + 1] = yuv444_odd<T>(cv[p + 1], cv[p + 2], first ? cv[p + 1] : cv[p], last2 ? cv[p + 2] : cv[p + 3]);
+        }
+        T *o = (T *)t.out[f] + (size_t)i * s.w + j;
+        if constexpr (sizeof(T) == 1) { // PX = 16
+            auto pk = [](const T *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+            __builtin_nontemporal_store((fvu4){ yw[0], yw[1], yw[2], yw[3] }, (fvu4 *)o);
+            __builtin_nontemporal_store((fvu4){ pk(uo), pk(uo + 4), pk(uo + 8), pk(uo + 12) }, (fvu4 *)(o + wh));
+            __builtin_nontemporal_store((fvu4){ pk(vo), pk(vo + 4), pk(vo + 8), pk(vo + 12) }, (fvu4 *)(o + 2 * wh));
+        } else { // PX = 4
+            __builtin_nontemporal_store((fvf4){ fin<float>((int)byte_of(yw[0], 0)), fin<float>((int)byte_of(yw[0], 1)), fin<float>((int)byte_of(yw[0], 2)),
+                                                fin<float>((int)byte_of(yw[0], 3)) },
+                                        (fvf4 *)o);
+            __builtin_nontemporal_store((fvf4){ uo[0], uo[1], uo[2], uo[3] }, (fvf4 *)(o + wh));
+            __builtin_nontemporal_store((fvf4){ vo[0], vo[1], vo[2], vo[3] }, (fvf4 *)(o + 2 * wh));
+        }
+    }
+}
+
 hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int py, int puv, int w, int h, hipStream_t stream) {
+    // row-pair kernels: PX pixels per thread (see above); the input alignment they need is PX bytes, the output's 16
+    static const int rp_pref = [] { const char *e = std::getenv("TSVPP_FMT_RP"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = single-row kernels
+    const int px = fourcc == TSVPP_UYVY ? (f32 ? 2 : 8) : (f32 ? 4 : 16);
+    bool rp = rp_pref != 0 && (fourcc == TSVPP_UYVY || fourcc == TSVPP_YUV444) && (w % px) == 0 && (h % 2) == 0 && (py % px) == 0 && (puv % px) == 0 &&
+              w >= 2 * px;
+    for (int f = 0; f < n && rp; f++)
+        rp = ((uintptr_t)t.out[f] & 15) == 0 && (((uintptr_t)t.y[f] | (uintptr_t)t.uv[f]) & (uintptr_t)(px - 1)) == 0;
+    if (rp && fourcc == TSVPP_YUV444 && ((size_t)w * h * (f32 ? 4 : 1)) % 16 != 0) rp = false; // the U and V planes start 16-byte aligned
+    if (rp) {
+        const dim3 block(FMT_BX, FMT_BY), grid((w / px + FMT_BX - 1) / FMT_BX, (h / 2 + FMT_BY - 1) / FMT_BY, n);
+        const FmtGeom g{ py, puv, w, h, 1 };
+        if (fourcc == TSVPP_UYVY) {
+            if (f32) hipLaunchKernelGGL((fmt_uyvy_rp<float, 2>), grid, block, 0, stream, t, g);
+            else hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 8>), grid, block, 0, stream, t, g);
+        } else {
+            if (f32) hipLaunchKernelGGL((fmt_yuv444_rp<float, 4>), grid, block, 0, stream, t, g);
+            else hipLaunchKernelGGL((fmt_yuv444_rp<uint8_t, 16>), grid, block, 0, stream, t, g);
+        }
+        return hipGetLastError();
+    }
     bool wide = (w % 4) == 0, a4 = (py % 4) == 0 && (puv % 4) == 0;
     for (int f = 0; f < n && wide; f++) wide = ((uintptr_t)t.out[f] & 15) == 0;
     for (int f = 0; f < n && a4; f++) a4 = (((uintptr_t)t.y[f] | (uintptr_t)t.uv[f]) & 3) == 0;

@@ -100,3 +100,26 @@ def test_format_batch_larger_than_one_launch(vpp, oracle, fcc):
         got = out[i].ravel()
         assert got.dtype == ref.dtype
         assert np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got, ref.view(np.uint32) if ref.dtype == np.float32 else ref)
+
+
+@pytest.mark.parametrize("fcc", [UYVY, YUV444])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("src,pitch,dst,rt", [((1280, 720), 1280, (0, 0), 0),      # rows of 80 / 160 / 320 / 640 threads: wave boundaries inside a row
+                                              ((2048, 6), 2048, (0, 0), 0),        # three chroma rows: the filter's clamps at both ends
+                                              ((32, 4), 32, (0, 0), 0),            # two threads per row (uint8 YUV444): both take the row-end path
+                                              ((64, 2), 64, (0, 0), 0),            # one chroma row
+                                              ((1040, 250), 1056, (0, 0), 0),      # padded pitch, width 16 k + 0 but not 64 k: partial last wave
+                                              ((1920, 1080), 1920, (1280, 720), 1),  # behind a resize: the tight NV12 intermediate
+                                              ((1920, 1080), 1920, (1024, 578), 3)])
+def test_row_pair_kernels(vpp, oracle, fcc, norm, src, pitch, dst, rt):
+    """The row-pair UYVY / YUV444 kernels (two output rows per thread, neighbours' chroma by wave shuffles) at the geometries
+    that exercise their wave-boundary, row-end and frame-end paths."""
+    y, uv = synth_nv12(src[0], src[1], seed=fcc * 13 + src[0] + rt, pitch=pitch)
+    got = run(vpp, y, uv, fcc, norm, (0, 0, 0, 0), dst, rt, width=src[0]).ravel()
+    ref, ow, oh = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=fcc, normalization=norm, nthreads=8, width=src[0])
+    assert got.dtype == ref.dtype and got.size == ref.size
+    if got.dtype == np.uint8:
+        bad = np.flatnonzero(got != ref)
+    else:
+        bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
+    assert bad.size == 0, (bad[:10], bad.size, ow, oh)
