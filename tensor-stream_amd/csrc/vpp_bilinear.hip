@@ -456,7 +456,9 @@ __device__ __forceinline__ RowPairGeo rows_from_rec(const RowRec &r) {
     g.cwy = r.c.x;
     return g;
 }
-template <int OUT>
+// SROWS: the workgroup is at least 64 thread tiles wide, so a wave's lanes share their output rows: the row-pair records are read
+// through a wave-uniform index -- scalar loads into SGPRs instead of 24 VGPRs per lane (80 -> 64 VGPRs: eight waves per SIMD).
+template <int OUT, bool SROWS>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_geo_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
     const TileId id = decode_tile(d);
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_geo_kernel(const Lau
     const uint4 *gc = d.geo_col + 4 * min(j0 >> 2, nquads - 1);
     const uint4 c0 = gc[0], c1 = gc[1], c2 = gc[2], c3 = gc[3];
     // row-pair records of this thread's first two row pairs (rpt <= 2 for every default shape: both are in flight during the staging)
-    const int pair0 = (i_first >> 1) + lyr0;
+    const int pair0 = SROWS ? __builtin_amdgcn_readfirstlane((i_first >> 1) + lyr0) : (i_first >> 1) + lyr0;
     RowRec ra = load_row_rec(d.geo_row, min(pair0, npairs - 1)), rb = load_row_rec(d.geo_row, min(pair0 + 1, npairs - 1));
 
     uint8_t *lds_y = lds_raw;
@@ -819,8 +821,11 @@ static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStr
 
 static hipError_t launch_bilinear_geo(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     switch (out) {
-#define TSVPP_GEO(O)                                                                               \
-    case O: hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O>), grid, block, lds, stream, d, t); break;
+#define TSVPP_GEO(O)                                                                                      \
+    case O:                                                                                               \
+        if (d.tx >= 64) hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O, true>), grid, block, lds, stream, d, t); \
+        else hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O, false>), grid, block, lds, stream, d, t);     \
+        break;
         TSVPP_GEO(O_U8_PLANAR) TSVPP_GEO(O_U8_MERGED) TSVPP_GEO(O_F32_PLANAR) TSVPP_GEO(O_F32_MERGED) TSVPP_GEO(O_NV12_U8)
         TSVPP_GEO(O_NV12_F32) TSVPP_GEO(O_Y800_U8) TSVPP_GEO(O_Y800_F32) TSVPP_GEO(O_HSV_F32)
 #undef TSVPP_GEO

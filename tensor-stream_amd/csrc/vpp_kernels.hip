@@ -1430,6 +1430,15 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         shapes[1][0] = shapes[0][0]; shapes[1][1] = shapes[0][1];
         shapes[0][0] = 64; shapes[0][1] = 4;
     }
+    // uint8 outputs on the integer window tile read host-built geometry tables (vpp_bilinear.hip): with workgroups 64 thread tiles
+    // wide a wave's lanes share their output rows and the row records are scalar loads -- measured (profiles/r02_geo_ab.txt)
+    // 1080p -> 720p planar 0.545 -> 0.570, merged 0.481 -> 0.506, 4K -> 1080p 0.706 -> 0.717 against 32 x 8
+    if (two_tap && !f32_out && d.bil_int == 2 && d.geo_pref && d.dma && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0 && d.dst_w >= 256) {
+        shapes[3][0] = shapes[2][0]; shapes[3][1] = shapes[2][1];
+        shapes[2][0] = shapes[1][0]; shapes[2][1] = shapes[1][1];
+        shapes[1][0] = shapes[0][0]; shapes[1][1] = shapes[0][1];
+        shapes[0][0] = 64; shapes[0][1] = 4;
+    }
     if (d.shape_tx > 0 && d.shape_ty > 0 && (d.shape_tx & (d.shape_tx - 1)) == 0 && d.shape_tx * d.shape_ty <= MAX_THREADS &&
         d.shape_tx * d.shape_ty >= 64) {
         shapes[0][0] = d.shape_tx;

@@ -25,9 +25,14 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     # whole tile rows per XCD: rows padded to a multiple of 8
     assert p["grid"] == (90 * 64 + 7) // 8 * 8 * 5
     # widths that do not fill 256-wide tiles stay on 128; uint8 outputs (VALU-bound) keep the tall thread tiles
-    assert plan((3840, 2160), (1920, 1080), B)["shape"] == "32x8"
+    assert plan((3840, 2160), (1920, 1080), B)["shape"] == "32x8" and plan((3840, 2160), (1920, 1080), B)["geo"] == 0
+    # ... and, with dyadic weights and 16-byte pitches, read host-built geometry tables on 64-wide workgroups (scalar row records)
     p = plan((1920, 1080), (1280, 720), B, norm=False)
-    assert (p["shape"], p["rpt"]) == ("32x8", 2)
+    assert (p["shape"], p["rpt"], p["geo"]) == ("64x4", 2, 1)
+    p = plan((1920, 1080), (1280, 720), B, norm=False, pitch=1928)      # pitch % 16 != 0: rows of differing misalignment
+    assert (p["shape"], p["rpt"], p["geo"]) == ("32x8", 2, 0)
+    p = plan((1920, 1080), (1366, 768), B, norm=False)                  # float weights: the tables were measured to lose
+    assert (p["shape"], p["geo"]) == ("32x8", 0)
 
 
 @pytest.mark.parametrize("src,dst,rt,kernel", [
