@@ -55,7 +55,7 @@ FOURCC = {"Y800": 0, "RGB24": 1, "BGR24": 2, "NV12": 3, "UYVY": 4, "YUV444": 5, 
 PLANES = {"PLANAR": 0, "MERGED": 1}
 # sources whose hash stamps a PMC traffic entry (tools/traffic_json.py writes it, lookup_traffic checks it)
 KERNEL_SOURCES = ["tensor-stream_amd/csrc/vpp_kernels.hip", "tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_bicubic_int.hip", "tensor-stream_amd/csrc/vpp_bilinear.hip",
-                  "tensor-stream_amd/csrc/vpp_area_box.hip", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h",
+                  "tensor-stream_amd/csrc/vpp_area_box.hip", "tensor-stream_amd/csrc/vpp_area_cols.hip", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h",
                   "tensor-stream_amd/csrc/vpp_formats.hip", "tensor-stream_amd/csrc/tsvpp_api.cpp"]
 
 
@@ -321,7 +321,7 @@ class GpuEngine:
         parallel.broadcast_coeffs(self.vpp, dist)
         self.fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=RESIZE[rt],
                                      pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
-        self.vpp.prepare(self.fp, src_w, src_h)
+        self.vpp.prepare(self.fp, src_w, src_h, n_frames=args.batch)  # tables + scratch for this batch size: the timed region allocates nothing
         B = args.batch
         # synthetic full-range NV12, distinct per frame / set / rank
         g = torch.Generator(device="cuda").manual_seed(1234 + rank)

@@ -125,7 +125,11 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
  * allocator -- e.g. before hipGraph capture: the AREA weight tables (the reference mallocs, copies and leaks them
  * per frame, src/Resize.cu:389-406,436-452) and, for UYVY / YUV444 behind a resize, the resized-NV12 scratch of
  * `stream` sized for calls of up to `n_frames` frames (the reference cudaMallocs that intermediate per frame,
- * src/Resize.cu:411-416).  tsvpp_prepare == tsvpp_prepare_batch(..., 0, NULL): tables only. */
+ * src/Resize.cu:411-416).  BILINEAR / AREA up-scale requests also get the geometry tables of the 2x2-tap kernel (tile
+ * footprints, per-column and per-row coordinates and weights, evaluated once on the host) for the tile shape a batch of
+ * `n_frames` frames runs with; a conversion that was not prepared builds them on first use -- except while its stream
+ * is being captured into a graph, where it never allocates and runs the kernel that computes coordinates itself (same
+ * bits).  tsvpp_prepare == tsvpp_prepare_batch(..., 0, NULL): tables only (single-frame tile shape). */
 int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height);
 int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height, int n_frames, void *stream);
 
