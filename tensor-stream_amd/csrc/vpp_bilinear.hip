@@ -117,7 +117,7 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
         return;
     }
 #endif
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+    color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
 // Integer form of the thread tile for requests whose weights are all multiples of 1/16 (LaunchDesc::bil_int; ratios 1.5,
@@ -178,7 +178,7 @@ __device__ __forceinline__ void bilinear_int_thread_tile(const LaunchDesc &d, co
             Yf[r][c] = (float)((sv >> 8) & 255u);
         }
     }
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+    color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
 
@@ -266,7 +266,7 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
             Yf[r][c] = (float)((vpair(tt, bb, g.wy[r]) >> 8) & 255u);
         }
     }
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+    color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
 // Window form of the FLOAT thread tile (LaunchDesc::bil_win: any weights, horizontal ratio <= 2): the same row windows and
@@ -311,7 +311,7 @@ __device__ __forceinline__ void bilinear_winf_thread_tile(const LaunchDesc &d, c
             Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
         }
     }
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
+    color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
 // table weight field: the float weight, or for the integer tiles the packed pair (16 - 16 w) | (16 w) << 16
