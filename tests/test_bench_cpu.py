@@ -75,7 +75,7 @@ def test_main_flow_on_the_stub_engine(flags, capsys, monkeypatch):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert isinstance(rf["touched_bytes"], int) and "traffic_source" in rf
     reps = res["timing"]["repeats_ms_per_step"]
-    assert len(reps) == 67 and res["timing"]["repeats"] == 67       # ceil(200 / 3 steps): at least 200 timed iterations
+    assert len(reps) == 134 and res["timing"]["repeats"] == 134     # ceil(400 / 3 steps): at least 200 timed iterations, the clock ramp in the tail
     assert sorted(reps)[len(reps) // 2] == res["ms_per_step"]       # the median repeat
     cb = res["cpu_baseline"]
     assert "error" not in cb and cb["value"] > 0 and cb["swscale"] == "unavailable in image"
