@@ -123,3 +123,28 @@ def test_row_pair_kernels(vpp, oracle, fcc, norm, src, pitch, dst, rt):
     else:
         bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
     assert bad.size == 0, (bad[:10], bad.size, ow, oh)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_row_pair_kernels_fuzz(vpp, oracle, chunk):
+    """Seeded fuzzing of UYVY / YUV444 at geometries the row-pair kernels take (widths that are multiples of 16, 16-byte pitches):
+    random sizes from one thread per row to several waves per row, with and without a resize in front."""
+    rng = np.random.default_rng(4242 + chunk)
+    for k in range(24):
+        w = int(rng.integers(2, 90)) * 16
+        h = int(rng.integers(1, 60)) * 2
+        pitch = w + 16 * int(rng.integers(0, 3))
+        fcc = int(rng.choice([UYVY, YUV444]))
+        norm = bool(rng.integers(0, 2))
+        dst, rt = (0, 0), 0
+        if rng.random() < 0.4:
+            dst, rt = (int(rng.integers(2, 40)) * 16, int(rng.integers(1, 40)) * 2), int(rng.integers(0, 4))
+        y, uv = synth_nv12(w, h, seed=5000 + 100 * chunk + k, pitch=pitch)
+        try:
+            ref, ow, oh = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=fcc, normalization=norm, nthreads=4, width=w)
+        except RuntimeError:
+            continue
+        got = run(vpp, y, uv, fcc, norm, (0, 0, 0, 0), dst, rt, width=w).ravel()
+        assert got.dtype == ref.dtype and got.size == ref.size
+        bad = np.flatnonzero(got.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, ((w, h, pitch, fcc, norm, dst, rt), bad[:8], bad.size)

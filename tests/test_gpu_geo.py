@@ -156,3 +156,44 @@ def test_geo_graph_capture(gvpp, oracle, prepared):
     torch.cuda.synchronize()
     ref, _, _ = oracle.convert(y, uv, dst=dst, resize_type=BILINEAR, fourcc=2, planes=0, normalization=True, nthreads=8, width=src[0])
     assert np.array_equal(out.cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8))
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_geo_fuzz(gvpp, oracle, chunk):
+    """Seeded differential fuzzing of the 2x2-tap requests with 16-byte pitches (the geometry-table kernel wherever the window
+    tiles apply, TSVPP_GEO=2): random sizes up to several tile columns / rows, crops with arbitrary origins, up- and down-scales,
+    dyadic and non-dyadic ratios, every output flavour, single frames and small batches."""
+    import tensor_stream as ts
+    rng = np.random.default_rng(977 + chunk)
+    for k in range(30):
+        w = int(rng.integers(8, 400)) * 2
+        h = int(rng.integers(4, 150)) * 2
+        pitch = (w + 15) // 16 * 16 + 16 * int(rng.integers(0, 3))
+        crop, sw, sh = (0, 0, 0, 0), w, h
+        if rng.random() < 0.3:
+            cw, ch = int(rng.integers(4, w // 2)) * 2, int(rng.integers(2, h // 2)) * 2
+            l, t = int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1))
+            if cw < w and ch < h:
+                crop, sw, sh = (l, t, l + cw, t + ch), cw, ch
+        if rng.random() < 0.6:   # dyadic ratios: the integer window tile
+            num, den = [(3, 2), (2, 1), (1, 2), (5, 4), (3, 4), (9, 8), (7, 4), (1, 1)][int(rng.integers(0, 8))]
+            dst = (max(2, sw * den // num // 2 * 2), max(2, sh * den // num // 2 * 2))
+        else:                    # anything from x0.5 to x2 down: float window tile between 1 and 1.45, float byte tile elsewhere
+            dst = (max(2, int(sw / rng.uniform(0.5, 2.0)) // 2 * 2), max(2, int(sh / rng.uniform(0.5, 2.0)) // 2 * 2))
+        if dst == (sw, sh):
+            continue
+        rt = int(rng.choice([BILINEAR, AREA]))
+        fourcc = int(rng.choice([1, 2, 0, 3, 4, 5, 6]))
+        planes = int(rng.integers(0, 2))
+        norm = bool(rng.integers(0, 2)) or fourcc == 6
+        n = int(rng.choice([1, 1, 3]))
+        y, uv = synth_nv12(w, h, seed=7000 + 100 * chunk + k, pitch=pitch)
+        fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+        ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=rt, fourcc=fourcc, planes=planes, normalization=norm, nthreads=4, width=w)
+        ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+        got = gvpp.Convert(ty, tuv, fp, width=w) if n == 1 else gvpp.convert_batch([ty] * n, [tuv] * n, fp, width=w)[n - 1]
+        torch.cuda.synchronize()
+        g = got.cpu().numpy().ravel()
+        assert g.size == ref.size, (w, h, pitch, crop, dst, rt, fourcc, planes, norm, n)
+        bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, ((w, h, pitch, crop, dst, rt, fourcc, planes, norm, n), bad[:6], bad.size)
