@@ -216,6 +216,7 @@ struct tsvpp_ctx {
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
+    int r32 = 1;                    // TSVPP_R32: streaming kernel for BILINEAR at exactly 3 : 2 with uint8 outputs
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
     GeoCache *geo = nullptr;        // ... their device copies, one set per (request geometry, tile shape)
     std::mutex area_mu;
@@ -314,6 +315,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA_POW2")) ctx->dma_pow2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_GEO")) ctx->geo_pref = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_R32")) ctx->r32 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
@@ -373,6 +375,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_cols_rows = ctx->area_cols_rows;
     d.num_cus = ctx->num_cus;
     d.geo_pref = ctx->geo_pref;
+    d.r32_pref = ctx->r32;
     d.geo_cache = ctx->geo;
 }
 

@@ -1,0 +1,204 @@
+// vpp_bilinear_r32.hip -- BILINEAR at the exact ratio 3 : 2 on both axes (1920x1080 -> 1280x720, 3840x2160 -> 2560x1440, 1280x720 ->
+// 854x480 is NOT one: 853.33) with uint8 outputs, as a streaming kernel without LDS.
+//
+// At ratio 1.5 the reference's coordinate (j + 0.5) * 1.5 - 0.5 (src/Resize.cu:276-303, one fma in its binary) is exactly 1.5 j + 0.25:
+// output column 2k taps source columns (3k, 3k + 1) with weights (3/4, 1/4), column 2k + 1 taps (3k + 1, 3k + 2) with (1/4, 3/4); no
+// clamp ever fires (the last tap is the last source column).  Rows alike.  Every weight is a multiple of 1/4, so the reference's float
+// blend is exact and equals ( sum of tap * (4 wx) (4 wy) ) >> 4 -- here with sixteenths like the integer thread tile of
+// vpp_bilinear.hip: ( sum tap * (16 wx)(16 wy) ) >> 8, products 144 / 48 / 48 / 16.  Those fit a byte: the WHOLE 2x2 blend of an output
+// value is v_dot4_u32_u8 on the source dwords with compile-time byte weights, accumulated across the two source rows through the
+// instruction's accumulator -- 2.5 instructions per value instead of 7 (two v_perm, two v_dot4, shift-or, v_dot2, convert).
+//
+// A thread converts 8 output columns x 4 output rows: source bytes [12 q, 12 q + 12) of 6 luma rows -- three aligned dwords per row,
+// dwordx3 loads straight from global memory, contiguous across the wave -- and the same 12 bytes of 3 chroma rows (4 output pairs = 6
+// source pairs; the two chroma output rows of the tile are the even / odd case of the same pattern).  No staging, no barrier, no
+// coordinate arithmetic: the uint8 1080p -> 720p launch of the LDS kernel is bound by exactly those.
+// The same tap positions serve the AREA down-scale at 3 : 2 (weight rows {1, 1/2}, {1/2, 1}: src/Resize.cu:160-212 with the pattern of
+// generateResizePattern(1.5); integer weights (2, 1) / (1, 2), value = SUM / 9 truncated -- area_quot, as in the dyadic AREA kernels) and
+// NEAREST (src/Resize.cu:249-265: the first tap alone), so KIND selects the weights and the final step; for NEAREST the untouched
+// third source row / column costs nothing (its loads are dead code).
+// Outputs: RGB24 / BGR24 uint8 planar (8-byte stores) and merged (24 bytes per lane and row, exchanged through LDS inside the wave so
+// that every store instruction writes a contiguous run), NV12, Y800.  fp32 outputs stay on vpp_bilinear_kernel: it sits on the
+// HBM floor of its write pattern already, and 8 fp32 columns per lane would split every line between two store instructions.
+#include "vpp_device.h"
+
+#pragma clang fp contract(off)
+
+namespace tsvpp {
+
+typedef uint32_t r32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t r32x2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t r32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// byte weights of dword d for the two taps of one output value: taps at bytes b0 and b0 + step of the 12-byte run, weights wa, wb
+constexpr uint32_t r32_w(int b0, int step, int wa, int wb, int d) {
+    uint32_t m = 0;
+    if (b0 / 4 == d) m |= (uint32_t)wa << (8 * (b0 % 4));
+    if ((b0 + step) / 4 == d) m |= (uint32_t)wb << (8 * ((b0 + step) % 4));
+    return m;
+}
+enum R32Kind : int { R32_BILINEAR = 0, R32_AREA = 1, R32_NEAREST = 2 };
+// integer weights of the (first, second) tap of an output index along one axis: BILINEAR sixteenths, AREA halves, NEAREST the tap itself
+template <int KIND> constexpr int r32_wfirst(bool odd) { return KIND == R32_BILINEAR ? (odd ? 4 : 12) : KIND == R32_AREA ? (odd ? 1 : 2) : 1; }
+template <int KIND> constexpr int r32_wsecond(bool odd) { return KIND == R32_BILINEAR ? (odd ? 12 : 4) : KIND == R32_AREA ? (odd ? 2 : 1) : 0; }
+
+// One output row of 8 values (luma: STEP 1) or 4 (U, V) pairs (chroma: STEP 2, values U0 V0 U1 V1 ...) from its two source rows.
+// ODD: the output row index is odd; columns alike.
+template <int KIND, bool CHROMA, bool ODD>
+__device__ __forceinline__ void r32_row(const uint32_t (&top)[3], const uint32_t (&bot)[3], float (&out)[8]) {
+    constexpr int wy0 = r32_wfirst<KIND>(ODD), wy1 = r32_wsecond<KIND>(ODD);
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        // luma: value v = column v: k = v / 2, first tap byte 3 k + (v & 1).  chroma: value v = component (v & 1) of pair column
+        // c = v / 2: first tap pair 3 (c / 2) + (c & 1), byte 2 * pair + component, second tap two bytes on
+        const int c = CHROMA ? (v >> 1) : v;
+        const int first = 3 * (c >> 1) + (c & 1);
+        const int b0 = CHROMA ? 2 * first + (v & 1) : first;
+        const int step = CHROMA ? 2 : 1;
+        const int wa = r32_wfirst<KIND>((c & 1) != 0), wb = r32_wsecond<KIND>((c & 1) != 0);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const uint32_t mt = r32_w(b0, step, wa * wy0, wb * wy0, d), mb = r32_w(b0, step, wa * wy1, wb * wy1, d);
+            if (mt != 0u) acc = __builtin_amdgcn_udot4(top[d], mt, acc, false);
+            if (mb != 0u) acc = __builtin_amdgcn_udot4(bot[d], mb, acc, false);
+        }
+        if constexpr (KIND == R32_BILINEAR) out[v] = (float)((acc >> 8) & 255u); // v_cvt_f32_ubyte1
+        else if constexpr (KIND == R32_AREA) out[v] = area_quot(acc, 3, 3, 1.0f / 9.0f);
+        else out[v] = (float)(acc & 255u);
+    }
+}
+__device__ __forceinline__ void r32_load(const uint8_t *p, uint32_t (&dw)[3]) {
+    const r32x3 v = *(const r32x3 *)p;
+    dw[0] = v.x; dw[1] = v.y; dw[2] = v.z;
+}
+__device__ __forceinline__ void st8(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int nt) {
+    const r32x2 v = { lo, hi };
+    if (nt) __builtin_nontemporal_store(v, (r32x2 *)(base + off));
+    else *(r32x2 *)(base + off) = v;
+}
+
+constexpr int R32_COLS = 8, R32_ROWS = 4;
+
+template <int OUT, int KIND>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const LaunchDesc d, const FrameTable t) {
+    const TileId id = decode_tile(d); // tiles of (8 tx) x (4 ty) output pixels
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int q = id.tx * d.tx + lx, n4 = id.ty * d.ty + ly;
+    const int j0 = R32_COLS * q, i0 = R32_ROWS * n4;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const int nt = d.nt_stores;
+    uint8_t *out = (uint8_t *)t.out[id.frame];
+    const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+
+    // all loads of the thread tile first: 6 luma rows, 3 chroma rows, 12 bytes each
+    uint32_t ys[6][3], cs[3][3];
+    const uint8_t *py = t.y[id.frame] + (size_t)(6 * n4) * (size_t)d.pitch_y + (size_t)(12 * q);
+#pragma unroll
+    for (int r = 0; r < 6; r++) r32_load(py + (size_t)r * (size_t)d.pitch_y, ys[r]);
+    if constexpr (!kLumaOnly<OUT>) {
+        const uint8_t *pc = t.uv[id.frame] + (size_t)(3 * n4) * (size_t)d.pitch_uv + (size_t)(12 * q);
+#pragma unroll
+        for (int r = 0; r < 3; r++) r32_load(pc + (size_t)r * (size_t)d.pitch_uv, cs[r]);
+    }
+
+    // merged uint8: the lanes of a run (the lanes of a wave that share the output rows) exchange their 24-byte row pieces through LDS
+    // so that the run's 24 A contiguous bytes leave as 16-byte stores (cf. MergedRun, vpp_device.h)
+    __shared__ __attribute__((aligned(16))) uint8_t slab[OUT == O_U8_MERGED ? MAX_THREADS * 24 : 16];
+    int run_m = 0, run_a = 1;
+    uint8_t *run_lds = nullptr;
+    if constexpr (OUT == O_U8_MERGED) {
+        const int len = min(d.tx, 64);
+        run_m = (int)threadIdx.x & (len - 1);
+        run_a = min(len, (d.dst_w - (j0 - R32_COLS * run_m)) / R32_COLS);
+        run_lds = slab + ((int)threadIdx.x - run_m) * 24;
+    }
+
+#pragma unroll
+    for (int rc = 0; rc < 2; rc++) { // chroma output row rc of the tile = luma output rows 2 rc, 2 rc + 1
+        float uvf[8] = { 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f }; // U0 V0 U1 V1 U2 V2 U3 V3
+        if constexpr (!kLumaOnly<OUT>) {
+            if (rc == 0) r32_row<KIND, true, false>(cs[0], cs[1], uvf);
+            else r32_row<KIND, true, true>(cs[1], cs[2], uvf);
+        }
+        float t0[4], tg[4], t2[4];
+        if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+        }
+        if constexpr (OUT == O_NV12_U8) {
+            const uint32_t cpix = plane + (uint32_t)((i0 >> 1) + rc) * (uint32_t)d.dst_w + (uint32_t)j0;
+            st8(out, cpix, pack_u8x4(uvf[0], uvf[1], uvf[2], uvf[3]), pack_u8x4(uvf[4], uvf[5], uvf[6], uvf[7]), nt);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = 2 * rc + rr; // luma output row of the tile: source rows 3 rc + rr, 3 rc + rr + 1
+            float yf[8];
+            if (rr == 0) r32_row<KIND, false, false>(ys[3 * rc], ys[3 * rc + 1], yf);
+            else r32_row<KIND, false, true>(ys[3 * rc + 1], ys[3 * rc + 2], yf);
+            const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+            if constexpr (OUT == O_NV12_U8 || OUT == O_Y800_U8) {
+                st8(out, pix, pack_u8x4(yf[0], yf[1], yf[2], yf[3]), pack_u8x4(yf[4], yf[5], yf[6], yf[7]), nt);
+            } else {
+                uint32_t pa[2], pb[2], pc[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    color_pack_row_u8<OUT == O_U8_PLANAR>(yf + 4 * h, t0 + 2 * h, tg + 2 * h, t2 + 2 * h, d.k, pa[h], pb[h], pc[h]);
+                if constexpr (OUT == O_U8_PLANAR) {
+                    st8(out, pix, pa[0], pa[1], nt);
+                    st8(out + plane, pix, pb[0], pb[1], nt);
+                    st8(out + 2 * (size_t)plane, pix, pc[0], pc[1], nt);
+                } else {
+                    if ((run_a & 1) == 0) { // 24 A bytes = 3 A / 2 chunks of 16
+                        uint32_t *w = (uint32_t *)(run_lds + 24 * run_m);
+                        w[0] = pa[0]; w[1] = pb[0]; w[2] = pc[0]; w[3] = pa[1]; w[4] = pb[1]; w[5] = pc[1];
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t row0 = 3u * (pix - (uint32_t)(R32_COLS * run_m)); // first byte of the run in this row
+                        const r32x4 v0 = *(const r32x4 *)(run_lds + 16 * run_m);
+                        *(r32x4 *)(out + row0 + 16u * (uint32_t)run_m) = v0;
+                        if (2 * run_m < run_a) {
+                            const r32x4 v1 = *(const r32x4 *)(run_lds + 16 * (run_a + run_m));
+                            *(r32x4 *)(out + row0 + 16u * (uint32_t)(run_a + run_m)) = v1;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    } else {
+                        st8(out, 3u * pix, pa[0], pb[0], 0);
+                        st8(out, 3u * pix + 8u, pc[0], pa[1], 0);
+                        st8(out, 3u * pix + 16u, pb[1], pc[1], 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KIND>
+static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
+    switch (out) {
+#define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND>), grid, block, 0, stream, d, t); break;
+        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8)
+#undef TSVPP_R32
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// d.r32: 1 BILINEAR, 2 AREA, 3 NEAREST (launch_fused)
+hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
+    dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
+    if (info) {
+        info->kernel = d.r32 == 1 ? "vpp_bilinear_r32_kernel<OUT,bilinear>" : d.r32 == 2 ? "vpp_bilinear_r32_kernel<OUT,area>" : "vpp_bilinear_r32_kernel<OUT,nearest>";
+        info->grid = (int)grid.x;
+        info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : 16;
+        return hipSuccess;
+    }
+    switch (d.r32) {
+    case 1: return launch_r32_k<R32_BILINEAR>(out, d, t, grid, block, stream);
+    case 2: return launch_r32_k<R32_AREA>(out, d, t, grid, block, stream);
+    case 3: return launch_r32_k<R32_NEAREST>(out, d, t, grid, block, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace tsvpp

@@ -477,6 +477,27 @@ template <int OUT, bool VEC> __device__ __forceinline__ MergedRun merged_run(con
     return r;
 }
 
+// Four pixels of one row -> three dwords of truncated, saturated bytes: PLANAR (channel 0 x 4, channel 1 x 4, channel 2 x 4) or
+// MERGED (the row's 12 contiguous bytes).  The arithmetic of color_store_row's uint8 vector branch, without the stores.
+template <bool PLANAR>
+__device__ __forceinline__ void color_pack_row_u8(const float *Yf, const float *t0, const float *tg, const float *t2, const tsvpp_coeffs &k,
+                                                  uint32_t &pa, uint32_t &pb, uint32_t &pc) {
+    f2 c0[2], c1[2], c2[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        f2 y = { Yf[2 * p], Yf[2 * p + 1] };
+        y = y - (f2){ k.y_offset, k.y_offset };
+        y.x = __builtin_fmaxf(0.0f, y.x);
+        y.y = __builtin_fmaxf(0.0f, y.y);
+        y = y * (f2){ k.y_scale, k.y_scale };
+        c0[p] = y + (f2){ t0[p], t0[p] };
+        c1[p] = y + (f2){ tg[p], tg[p] };
+        c2[p] = y + (f2){ t2[p], t2[p] };
+    }
+    if constexpr (PLANAR) pack_u8x12_rtz(c0[0].x, c0[0].y, c0[1].x, c0[1].y, c1[0].x, c1[0].y, c1[1].x, c1[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y, pa, pb, pc);
+    else pack_u8x12_rtz(c0[0].x, c1[0].x, c2[0].x, c0[0].y, c1[0].y, c2[0].y, c0[1].x, c1[1].x, c2[1].x, c0[1].y, c1[1].y, c2[1].y, pa, pb, pc);
+}
+
 // One output row of this thread: 4 pixels -> 3 channels, converted and stored.
 template <int OUT, bool VEC>
 __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float t0[2], const float tg[2], const float t2[2],

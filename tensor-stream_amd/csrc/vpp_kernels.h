@@ -101,6 +101,7 @@ struct LaunchDesc {
     const int4 *geo_tx, *geo_ty;
     const uint4 *geo_col, *geo_row;
     int geo_pref, geo, geo_build;
+    int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
     GeoCache *geo_cache;
 };
 
@@ -136,6 +137,9 @@ hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
 hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
+
+// BILINEAR at exactly 3 : 2 on both axes, uint8 outputs, straight from global memory (vpp_bilinear_r32.hip).
+hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // The 2x2-tap kernel family (vpp_bilinear.hip): BILINEAR / AREA up-scale, plain or persistent.
 hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &d, const FrameTable &t, unsigned grid_x, size_t lds_bytes,

@@ -1285,6 +1285,11 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
         return launch_point<OUT>(d, t, lds_bytes, stream, info);
+    if constexpr (MODE == M_BILINEAR || MODE == M_AREA_DOWN || MODE == M_NEAREST) {
+        if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED || OUT == O_NV12_U8 || OUT == O_Y800_U8) {
+            if (d.r32) return launch_bilinear_r32((OutKind)OUT, d, t, stream, info);
+        }
+    }
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
             // persistent variant: two LDS tile sets filled by LDS-DMA
@@ -1652,8 +1657,32 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     }
     if (!staged) d.dma = 0;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
+    // BILINEAR at exactly 3 : 2 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
+    // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
+    // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
+    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
+    d.r32 = 0;
+    if (d.r32_pref && u8_flavour && vec && !d.force_gather && d.in_aligned4 && 2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h &&
+        (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
+        if (mode == M_BILINEAR) d.r32 = 1;
+        else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 2 && d.ny == 2 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 2; // rows {1, 1/2}, {1/2, 1}
+        else if (mode == M_NEAREST) d.r32 = 3;
+    }
+    if (d.r32) {
+        d.point_kind = PK_NONE;
+        d.area_direct = 0;
+        staged = false;
+        lds_bytes = 0;
+        d.dma = 0;
+        d.rpt = 1;
+        d.geo = 0;
+        if (!(d.shape_tx > 0 && d.shape_ty > 0)) { // measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16
+            d.tx = 64;
+            d.ty = 4;
+        }
+    }
     d.tx_shift = slot_shift_for(d.tx);
-    const int tile_w = d.tx * PXW, tile_h = d.ty * PXH * d.rpt;
+    const int tile_w = d.tx * (d.r32 ? 8 : PXW), tile_h = d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;

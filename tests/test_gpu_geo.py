@@ -35,7 +35,7 @@ def gvpp():
     """A context with TSVPP_GEO=2: the geometry tables wherever they apply (the default uses them for uint8 outputs with
     dyadic weights only, where they were measured to win)."""
     import tensor_stream
-    with _Env(TSVPP_GEO="2"):
+    with _Env(TSVPP_GEO="2", TSVPP_R32="0"):   # (the streaming 3 : 2 kernel would take the uint8 1080p -> 720p cases)
         v = tensor_stream.VideoProcessor(device=0, max_consumers=2)
     yield v
     v.Close()
@@ -53,7 +53,7 @@ def check(v, oracle, y, uv, w, dst, n=1, geo=1, **kw):
     crop = kw.get("crop", (0, 0, 0, 0))
     # the request takes the geometry tables (host logic; the crop must not change the pitch)
     if not any(k.startswith("TSVPP_") for k in os.environ):   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
-        with _Env(TSVPP_GEO="2"):
+        with _Env(TSVPP_GEO="2", TSVPP_R32="0"):
             assert V.describe(fp, w, h, pitch=y.shape[1], n_frames=n)["geo"] == geo, (w, h, dst, kw)
     ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
     if n == 1:
@@ -123,7 +123,7 @@ def test_geo_tall_thread_tiles_and_knob_off(oracle):
     import tensor_stream
     y, uv = synth_nv12(1920, 1080, seed=117)
     for env in ({"TSVPP_RPT": "4"}, {"TSVPP_RPT": "3"}, {"TSVPP_GEO": "0"}, {}):   # {}: the default selection (uint8 + dyadic weights: tables)
-        with _Env(**env):
+        with _Env(TSVPP_R32="0", **env):
             v = tensor_stream.VideoProcessor(device=0)
         fp = params((1280, 720))
         got = v.convert_batch([torch.from_numpy(y).cuda()] * 64, [torch.from_numpy(uv).cuda()] * 64, fp, width=1920)

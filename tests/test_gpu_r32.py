@@ -1,0 +1,84 @@
+"""GPU: the streaming BILINEAR kernel for the exact ratio 3 : 2 with uint8 outputs (vpp_bilinear_r32_kernel: the whole 2x2 blend as
+v_dot4 on source dwords with compile-time byte weights, no LDS) against the oracle, bit for bit: every flavour it takes, partial tile
+columns / rows, odd and even partial runs of the merged-output exchange, crops, batches; requests it cannot take fall back."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import synth_nv12
+
+pytestmark = pytest.mark.gpu
+NEAREST, BILINEAR, AREA = 0, 1, 3
+Y800, RGB24, BGR24, NV12, UYVY, YUV444 = 0, 1, 2, 3, 4, 5
+
+
+def check(vpp, oracle, y, uv, w, dst, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0), n=1, r32=True, norm=False, rt=BILINEAR):
+    import tensor_stream as ts
+    from tensor_stream import vpp as V
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+    if not any(k.startswith("TSVPP_") for k in os.environ):
+        k = V.describe(fp, w, y.shape[0], pitch=y.shape[1], n_frames=n)["kernel"]
+        assert k.startswith("vpp_bilinear_r32_kernel") == r32, (k, w, y.shape, dst, crop)
+    ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+    got = vpp.Convert(ty, tuv, fp, width=w) if n == 1 else vpp.convert_batch([ty] * n, [tuv] * n, fp, width=w)
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=rt, fourcc=fourcc, planes=planes, normalization=norm, nthreads=8, width=w)
+    for g in ([got] if n == 1 else [got[0], got[n - 1]]):
+        g = g.cpu().numpy().ravel()
+        assert g.size == ref.size
+        bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, (w, y.shape, dst, rt, fourcc, planes, crop, n, bad[:8], bad.size)
+
+
+@pytest.mark.parametrize("src,pitch", [((1920, 1080), 2048), ((3840, 2160), 3840), ((960, 540), 960), ((48, 24), 48), ((1944, 1092), 1952),
+                                       ((444, 66), 444),     # 37 threads per row: a partial run of 5 lanes (odd: direct stores)
+                                       ((456, 66), 460)])    # 38 threads per row: a partial run of 6 lanes (even: exchanged)
+@pytest.mark.parametrize("fourcc,planes", [(RGB24, 0), (BGR24, 1), (RGB24, 1), (NV12, 1), (Y800, 1)])
+@pytest.mark.parametrize("rt", [BILINEAR, AREA, NEAREST])
+def test_r32_sizes_and_flavours(vpp, oracle, src, pitch, fourcc, planes, rt):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + fourcc + planes + rt, pitch=pitch)
+    check(vpp, oracle, y, uv, src[0], (src[0] * 2 // 3, src[1] * 2 // 3), fourcc=fourcc, planes=planes, rt=rt)
+
+
+def test_r32_batches_crops_two_pass_fallbacks(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=31, pitch=2048)
+    check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=BGR24, planes=1, n=64)
+    check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=RGB24, planes=1, n=64, rt=AREA)
+    check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=RGB24, planes=0, n=64, rt=NEAREST)
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(12, 6, 972, 546), rt=AREA, planes=1)
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(12, 6, 972, 546), rt=NEAREST)
+    check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=RGB24, planes=0, n=3)
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(4, 2, 964, 542))                       # origin a multiple of 4: pointers stay dword-aligned
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(8, 7, 968, 547), planes=1)
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(6, 2, 966, 542), r32=False)            # misaligned origin: the LDS kernel
+    check(vpp, oracle, y, uv, 1920, (640, 360), crop=(5, 3, 965, 543), planes=1, r32=False)  # odd origin (U / V swapped)
+    check(vpp, oracle, y, uv, 1920, (1280, 720), norm=True, r32=False)                       # fp32 outputs stay on vpp_bilinear_kernel
+    for fcc in (UYVY, YUV444):                                                               # pass 1 of the two-pass formats
+        check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=fcc, planes=1)
+        check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=fcc, planes=1, norm=True)
+    y, uv = synth_nv12(966, 546, seed=32, pitch=976)
+    check(vpp, oracle, y, uv, 966, (644, 364), r32=False)                                    # 644 = 8 k + 4
+    y, uv = synth_nv12(960, 543 * 2, seed=33)
+    check(vpp, oracle, y, uv, 960, (640, 724))                                               # 181 row quads
+    y, uv = synth_nv12(960, 546, seed=34)
+    check(vpp, oracle, y, uv, 960, (640, 364))                                               # 91 row quads: a partial last tile row
+    for val in (0, 255):
+        yy = np.full((72, 96), val, np.uint8)
+        uu = np.full((36, 96), 255 - val, np.uint8)
+        for rt in (BILINEAR, AREA, NEAREST):
+            check(vpp, oracle, yy, uu, 96, (64, 48), planes=1, rt=rt)
+            check(vpp, oracle, yy, uu, 96, (64, 48), planes=0, rt=rt)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_r32_fuzz(vpp, oracle, chunk):
+    rng = np.random.default_rng(3200 + chunk)
+    for k in range(24):
+        dw, dh = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 4
+        w, h = dw * 3 // 2, dh * 3 // 2
+        pitch = (w + 3) // 4 * 4 + 4 * int(rng.integers(0, 4))
+        fourcc, planes = [(RGB24, 0), (RGB24, 1), (BGR24, 0), (BGR24, 1), (NV12, 1), (Y800, 1), (UYVY, 1), (YUV444, 1)][int(rng.integers(0, 8))]
+        y, uv = synth_nv12(w, h, seed=8000 + 100 * chunk + k, pitch=pitch)
+        check(vpp, oracle, y, uv, w, (dw, dh), fourcc=fourcc, planes=planes, n=int(rng.choice([1, 1, 2])), rt=int(rng.choice([NEAREST, BILINEAR, AREA])))

@@ -27,10 +27,17 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     # widths that do not fill 256-wide tiles stay on 128; uint8 outputs (VALU-bound) keep the tall thread tiles
     assert plan((3840, 2160), (1920, 1080), B)["shape"] == "32x8" and plan((3840, 2160), (1920, 1080), B)["geo"] == 0
     # ... and, with dyadic weights and 16-byte pitches, read host-built geometry tables on 64-wide workgroups (scalar row records)
-    p = plan((1920, 1080), (1280, 720), B, norm=False)
-    assert (p["shape"], p["rpt"], p["geo"]) == ("64x4", 2, 1)
-    p = plan((1920, 1080), (1280, 720), B, norm=False, pitch=1928)      # pitch % 16 != 0: rows of differing misalignment
+    p = plan((3840, 2160), (1920, 1080), B, norm=False)
+    assert (p["kernel"], p["shape"], p["rpt"], p["geo"]) == ("vpp_bilinear_kernel<bilinear,OUT>", "64x4", 2, 1)
+    p = plan((3840, 2160), (1920, 1080), B, norm=False, pitch=3848)     # pitch % 16 != 0: rows of differing misalignment
     assert (p["shape"], p["rpt"], p["geo"]) == ("32x8", 2, 0)
+    # uint8 outputs at exactly 3 : 2 (1080p -> 720p): the streaming kernel without LDS -- BILINEAR, AREA and NEAREST; fp32 and BICUBIC not
+    for rt, kind in ((B, "bilinear"), (A, "area"), (N, "nearest")):
+        p = plan((1920, 1080), (1280, 720), rt, norm=False, pitch=2048)
+        assert (p["kernel"], p["shape"], p["tiles"], p["geo"]) == ("vpp_bilinear_r32_kernel<OUT,%s>" % kind, "64x4", "3x45", 0)
+    assert plan((1920, 1080), (1280, 720), C, norm=False)["kernel"] == "vpp_bicubic_int_kernel<OUT>"
+    assert plan((1920, 1080), (1280, 720), B, norm=False, pitch=1922)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"   # planes not dword-aligned
+    assert plan((1926, 1080), (1284, 720), B, norm=False)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"               # width 8 k + 4
     p = plan((1920, 1080), (1366, 768), B, norm=False)                  # float weights: the tables were measured to lose
     assert (p["shape"], p["geo"]) == ("32x8", 0)
 
@@ -81,8 +88,9 @@ def test_small_outputs_keep_two_row_thread_tiles():
     for n in (8, 64):
         assert plan((1920, 1080), (1280, 720), B, n_frames=n)["rpt"] == 1
     assert plan((3840, 2160), (1920, 1080), B, n_frames=64)["rpt"] == 1
-    assert plan((1920, 1080), (1280, 720), B, n_frames=8, norm=False)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
-    assert plan((1920, 1080), (1280, 720), B, n_frames=64, norm=False)["rpt"] == 2   # 14720 >= 12288
+    # (pitch 1922: planes not dword-aligned, so neither the streaming 3 : 2 kernel nor the geometry tables apply -- the plain LDS kernel)
+    assert plan((1920, 1080), (1280, 720), B, n_frames=8, norm=False, pitch=1922)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
+    assert plan((1920, 1080), (1280, 720), B, n_frames=64, norm=False, pitch=1922)["rpt"] == 2   # 14720 >= 12288
     assert plan((1920, 1080), (960, 540), B, n_frames=64, norm=False)["rpt"] == 1    # 8704
     # dyadic AREA: most resident workgroups first; since round 2 the LDS-DMA layout is as compact as the register-staged one
     # (any number of chunks per row), so it wins the tie: 1080p -> 960x540 two-row tiles, 21 KiB, LDS-DMA
@@ -91,7 +99,7 @@ def test_small_outputs_keep_two_row_thread_tiles():
     p = plan((1920, 1080), (1536, 864), A, n_frames=64)                  # >= 5 per CU either way: taller tile, LDS-DMA
     assert (p["rpt"], p["dma"]) == (2, 1)
     # the compact layout: the uint8 headline tile needs 20 KiB (round 1: 26.9 KiB with power-of-two row pitches)
-    assert plan((1920, 1080), (1280, 720), B, norm=False)["lds"] <= 20 * 1024
+    assert plan((1920, 1080), (1280, 720), B, norm=False, pitch=1922)["lds"] <= 20 * 1024
 
 
 def test_output_flavours_share_the_sampling_kernels():
