@@ -17,6 +17,9 @@
 // generateResizePattern(1.5); integer weights (2, 1) / (1, 2), value = SUM / 9 truncated -- area_quot, as in the dyadic AREA kernels) and
 // NEAREST (src/Resize.cu:249-265: the first tap alone), so KIND selects the weights and the final step; for NEAREST the untouched
 // third source row / column costs nothing (its loads are dead code).
+// RATIO 4 (template parameter P2 = twice the ratio) is the 2 : 1 case (3840x2160 -> 1920x1080, 1920x1080 -> 960x540) on the same skeleton:
+// 1.5 j + 0.25 becomes 2 j + 0.5 -- taps (2 j, 2 j + 1) with weights (1/2, 1/2) for every index --, a thread's 8 columns are 16 source bytes
+// (dwordx4 loads) and its 4 rows 8 luma / 4 chroma source rows; AREA sums the 2 x 2 box and divides by 4, NEAREST takes tap 2 j.
 // Outputs: RGB24 / BGR24 uint8 planar (8-byte stores) and merged (24 bytes per lane and row, exchanged through LDS inside the wave so
 // that every store instruction writes a contiguous run), NV12, Y800.  fp32 outputs stay on vpp_bilinear_kernel: it sits on the
 // HBM floor of its write pattern already, and 8 fp32 columns per lane would split every line between two store instructions.
@@ -38,39 +41,51 @@ constexpr uint32_t r32_w(int b0, int step, int wa, int wb, int d) {
     return m;
 }
 enum R32Kind : int { R32_BILINEAR = 0, R32_AREA = 1, R32_NEAREST = 2 };
-// integer weights of the (first, second) tap of an output index along one axis: BILINEAR sixteenths, AREA halves, NEAREST the tap itself
-template <int KIND> constexpr int r32_wfirst(bool odd) { return KIND == R32_BILINEAR ? (odd ? 4 : 12) : KIND == R32_AREA ? (odd ? 1 : 2) : 1; }
-template <int KIND> constexpr int r32_wsecond(bool odd) { return KIND == R32_BILINEAR ? (odd ? 12 : 4) : KIND == R32_AREA ? (odd ? 2 : 1) : 0; }
+// integer weights of the (first, second) tap of an output index along one axis: BILINEAR sixteenths, AREA halves (3 : 2) or ones (2 : 1),
+// NEAREST the tap itself.  At 2 : 1 (P2 == 4) every index has the same pair.
+template <int KIND, int P2> constexpr int r32_wfirst(bool odd) {
+    return P2 == 4 ? (KIND == R32_BILINEAR ? 8 : 1) : KIND == R32_BILINEAR ? (odd ? 4 : 12) : KIND == R32_AREA ? (odd ? 1 : 2) : 1;
+}
+template <int KIND, int P2> constexpr int r32_wsecond(bool odd) {
+    return P2 == 4 ? (KIND == R32_BILINEAR ? 8 : KIND == R32_AREA ? 1 : 0) : KIND == R32_BILINEAR ? (odd ? 12 : 4) : KIND == R32_AREA ? (odd ? 2 : 1) : 0;
+}
+// first tap of output index c within the thread's run, in samples: 3 : 2 -> 3 (c / 2) + (c & 1); 2 : 1 -> 2 c
+template <int P2> constexpr int r32_first(int c) { return P2 == 4 ? 2 * c : 3 * (c >> 1) + (c & 1); }
 
-// One output row of 8 values (luma: STEP 1) or 4 (U, V) pairs (chroma: STEP 2, values U0 V0 U1 V1 ...) from its two source rows.
-// ODD: the output row index is odd; columns alike.
-template <int KIND, bool CHROMA, bool ODD>
-__device__ __forceinline__ void r32_row(const uint32_t (&top)[3], const uint32_t (&bot)[3], float (&out)[8]) {
-    constexpr int wy0 = r32_wfirst<KIND>(ODD), wy1 = r32_wsecond<KIND>(ODD);
+// One output row of 8 values (luma: STEP 1) or 4 (U, V) pairs (chroma: STEP 2, values U0 V0 U1 V1 ...) from its two source rows of P2
+// dwords.  ODD: the output row index is odd; columns alike.
+template <int KIND, int P2, bool CHROMA, bool ODD>
+__device__ __forceinline__ void r32_row(const uint32_t (&top)[P2], const uint32_t (&bot)[P2], float (&out)[8]) {
+    constexpr int wy0 = r32_wfirst<KIND, P2>(ODD), wy1 = r32_wsecond<KIND, P2>(ODD);
 #pragma unroll
     for (int v = 0; v < 8; v++) {
-        // luma: value v = column v: k = v / 2, first tap byte 3 k + (v & 1).  chroma: value v = component (v & 1) of pair column
-        // c = v / 2: first tap pair 3 (c / 2) + (c & 1), byte 2 * pair + component, second tap two bytes on
+        // luma: value v = column v.  chroma: value v = component (v & 1) of pair column c = v / 2: byte 2 * pair + component, second tap
+        // two bytes on
         const int c = CHROMA ? (v >> 1) : v;
-        const int first = 3 * (c >> 1) + (c & 1);
+        const int first = r32_first<P2>(c);
         const int b0 = CHROMA ? 2 * first + (v & 1) : first;
         const int step = CHROMA ? 2 : 1;
-        const int wa = r32_wfirst<KIND>((c & 1) != 0), wb = r32_wsecond<KIND>((c & 1) != 0);
+        const int wa = r32_wfirst<KIND, P2>((c & 1) != 0), wb = r32_wsecond<KIND, P2>((c & 1) != 0);
         uint32_t acc = 0;
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
+        for (int d = 0; d < P2; d++) {
             const uint32_t mt = r32_w(b0, step, wa * wy0, wb * wy0, d), mb = r32_w(b0, step, wa * wy1, wb * wy1, d);
             if (mt != 0u) acc = __builtin_amdgcn_udot4(top[d], mt, acc, false);
             if (mb != 0u) acc = __builtin_amdgcn_udot4(bot[d], mb, acc, false);
         }
         if constexpr (KIND == R32_BILINEAR) out[v] = (float)((acc >> 8) & 255u); // v_cvt_f32_ubyte1
-        else if constexpr (KIND == R32_AREA) out[v] = area_quot(acc, 3, 3, 1.0f / 9.0f);
+        else if constexpr (KIND == R32_AREA) out[v] = P2 == 4 ? area_quot(acc, 2, 2, 0.25f) : area_quot(acc, 3, 3, 1.0f / 9.0f);
         else out[v] = (float)(acc & 255u);
     }
 }
-__device__ __forceinline__ void r32_load(const uint8_t *p, uint32_t (&dw)[3]) {
-    const r32x3 v = *(const r32x3 *)p;
-    dw[0] = v.x; dw[1] = v.y; dw[2] = v.z;
+template <int P2> __device__ __forceinline__ void r32_load(const uint8_t *p, uint32_t (&dw)[P2]) {
+    if constexpr (P2 == 3) {
+        const r32x3 v = *(const r32x3 *)p;
+        dw[0] = v.x; dw[1] = v.y; dw[2] = v.z;
+    } else {
+        const r32x4 v = *(const r32x4 *)p;
+        dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+    }
 }
 __device__ __forceinline__ void st8(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int nt) {
     const r32x2 v = { lo, hi };
@@ -80,8 +95,9 @@ __device__ __forceinline__ void st8(uint8_t *base, uint32_t off, uint32_t lo, ui
 
 constexpr int R32_COLS = 8, R32_ROWS = 4;
 
-template <int OUT, int KIND>
+template <int OUT, int KIND, int P2>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const LaunchDesc d, const FrameTable t) {
+    constexpr int NYR = 2 * P2, NCR = P2, RUN = 4 * P2; // luma / chroma source rows of a thread tile, source bytes per row
     const TileId id = decode_tile(d); // tiles of (8 tx) x (4 ty) output pixels
     if (!id.valid) return;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
@@ -92,15 +108,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
     uint8_t *out = (uint8_t *)t.out[id.frame];
     const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
 
-    // all loads of the thread tile first: 6 luma rows, 3 chroma rows, 12 bytes each
-    uint32_t ys[6][3], cs[3][3];
-    const uint8_t *py = t.y[id.frame] + (size_t)(6 * n4) * (size_t)d.pitch_y + (size_t)(12 * q);
+    // all loads of the thread tile first (3 : 2: 6 luma rows, 3 chroma rows, 12 bytes each; 2 : 1: 8 and 4 rows of 16 bytes)
+    uint32_t ys[NYR][P2], cs[NCR][P2];
+    const uint8_t *py = t.y[id.frame] + (size_t)(NYR * n4) * (size_t)d.pitch_y + (size_t)(RUN * q);
 #pragma unroll
-    for (int r = 0; r < 6; r++) r32_load(py + (size_t)r * (size_t)d.pitch_y, ys[r]);
+    for (int r = 0; r < NYR; r++) r32_load<P2>(py + (size_t)r * (size_t)d.pitch_y, ys[r]);
     if constexpr (!kLumaOnly<OUT>) {
-        const uint8_t *pc = t.uv[id.frame] + (size_t)(3 * n4) * (size_t)d.pitch_uv + (size_t)(12 * q);
+        const uint8_t *pc = t.uv[id.frame] + (size_t)(NCR * n4) * (size_t)d.pitch_uv + (size_t)(RUN * q);
 #pragma unroll
-        for (int r = 0; r < 3; r++) r32_load(pc + (size_t)r * (size_t)d.pitch_uv, cs[r]);
+        for (int r = 0; r < NCR; r++) r32_load<P2>(pc + (size_t)r * (size_t)d.pitch_uv, cs[r]);
     }
 
     // merged uint8: the lanes of a run (the lanes of a wave that share the output rows) exchange their 24-byte row pieces through LDS
@@ -119,8 +135,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
     for (int rc = 0; rc < 2; rc++) { // chroma output row rc of the tile = luma output rows 2 rc, 2 rc + 1
         float uvf[8] = { 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f, 128.0f }; // U0 V0 U1 V1 U2 V2 U3 V3
         if constexpr (!kLumaOnly<OUT>) {
-            if (rc == 0) r32_row<KIND, true, false>(cs[0], cs[1], uvf);
-            else r32_row<KIND, true, true>(cs[1], cs[2], uvf);
+            // chroma output row rc: first source row r32_first(rc) = 0 / 1 (3 : 2) or 0 / 2 (2 : 1)
+            if (rc == 0) r32_row<KIND, P2, true, false>(cs[0], cs[1], uvf);
+            else r32_row<KIND, P2, true, true>(cs[r32_first<P2>(1)], cs[r32_first<P2>(1) + 1], uvf);
         }
         float t0[4], tg[4], t2[4];
         if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED) {
@@ -133,10 +150,10 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         }
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const int r = 2 * rc + rr; // luma output row of the tile: source rows 3 rc + rr, 3 rc + rr + 1
+            const int r = 2 * rc + rr; // luma output row of the tile: source rows r32_first(r), r32_first(r) + 1
             float yf[8];
-            if (rr == 0) r32_row<KIND, false, false>(ys[3 * rc], ys[3 * rc + 1], yf);
-            else r32_row<KIND, false, true>(ys[3 * rc + 1], ys[3 * rc + 2], yf);
+            if (rr == 0) r32_row<KIND, P2, false, false>(ys[r32_first<P2>(2 * rc)], ys[r32_first<P2>(2 * rc) + 1], yf);
+            else r32_row<KIND, P2, false, true>(ys[r32_first<P2>(2 * rc + 1)], ys[r32_first<P2>(2 * rc + 1) + 1], yf);
             const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
             if constexpr (OUT == O_NV12_U8 || OUT == O_Y800_U8) {
                 st8(out, pix, pack_u8x4(yf[0], yf[1], yf[2], yf[3]), pack_u8x4(yf[4], yf[5], yf[6], yf[7]), nt);
@@ -173,10 +190,10 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
     }
 }
 
-template <int KIND>
+template <int KIND, int P2>
 static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
-#define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND>), grid, block, 0, stream, d, t); break;
+#define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
         TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8)
 #undef TSVPP_R32
     default: return hipErrorInvalidValue;
@@ -184,19 +201,25 @@ static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTabl
     return hipGetLastError();
 }
 
-// d.r32: 1 BILINEAR, 2 AREA, 3 NEAREST (launch_fused)
+// d.r32: 1 BILINEAR, 2 AREA, 3 NEAREST at 3 : 2; 4 / 5 / 6 the same at 2 : 1 (launch_fused)
 hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     if (info) {
-        info->kernel = d.r32 == 1 ? "vpp_bilinear_r32_kernel<OUT,bilinear>" : d.r32 == 2 ? "vpp_bilinear_r32_kernel<OUT,area>" : "vpp_bilinear_r32_kernel<OUT,nearest>";
+        static const char *const names[6] = { "vpp_bilinear_r32_kernel<OUT,bilinear,3:2>", "vpp_bilinear_r32_kernel<OUT,area,3:2>", "vpp_bilinear_r32_kernel<OUT,nearest,3:2>",
+                                              "vpp_bilinear_r32_kernel<OUT,bilinear,2:1>", "vpp_bilinear_r32_kernel<OUT,area,2:1>", "vpp_bilinear_r32_kernel<OUT,nearest,2:1>" };
+        if (d.r32 < 1 || d.r32 > 6) return hipErrorInvalidValue;
+        info->kernel = names[d.r32 - 1];
         info->grid = (int)grid.x;
         info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : 16;
         return hipSuccess;
     }
     switch (d.r32) {
-    case 1: return launch_r32_k<R32_BILINEAR>(out, d, t, grid, block, stream);
-    case 2: return launch_r32_k<R32_AREA>(out, d, t, grid, block, stream);
-    case 3: return launch_r32_k<R32_NEAREST>(out, d, t, grid, block, stream);
+    case 1: return launch_r32_k<R32_BILINEAR, 3>(out, d, t, grid, block, stream);
+    case 2: return launch_r32_k<R32_AREA, 3>(out, d, t, grid, block, stream);
+    case 3: return launch_r32_k<R32_NEAREST, 3>(out, d, t, grid, block, stream);
+    case 4: return launch_r32_k<R32_BILINEAR, 4>(out, d, t, grid, block, stream);
+    case 5: return launch_r32_k<R32_AREA, 4>(out, d, t, grid, block, stream);
+    case 6: return launch_r32_k<R32_NEAREST, 4>(out, d, t, grid, block, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1657,16 +1657,23 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     }
     if (!staged) d.dma = 0;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
-    // BILINEAR at exactly 3 : 2 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
+    // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
     // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
     // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
     const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
     d.r32 = 0;
-    if (d.r32_pref && u8_flavour && vec && !d.force_gather && d.in_aligned4 && 2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h &&
-        (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
-        if (mode == M_BILINEAR) d.r32 = 1;
-        else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 2 && d.ny == 2 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 2; // rows {1, 1/2}, {1/2, 1}
-        else if (mode == M_NEAREST) d.r32 = 3;
+    if (d.r32_pref && u8_flavour && vec && !d.force_gather && d.in_aligned4 && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
+        if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) {
+            if (mode == M_BILINEAR) d.r32 = 1;
+            else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 2 && d.ny == 2 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 2; // rows {1, 1/2}, {1/2, 1}
+            else if (mode == M_NEAREST) d.r32 = 3;
+        } else if (d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) {
+            // BILINEAR 2 : 1, planar, large outputs: the LDS kernel with geometry tables measured faster (4K -> 1080p 0.721 vs 0.688 same box;
+            // merged 0.681 vs 0.684; 1080p -> 540p 0.579 vs 0.630): streaming only below 1.5 Mpixel there (TSVPP_R32=2 forces it)
+            if (mode == M_BILINEAR) d.r32 = (out == O_U8_PLANAR && (long)d.dst_w * d.dst_h >= 1500000L && d.r32_pref != 2) ? 0 : 4;
+            else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 1 && d.ny == 1 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 5; // one row {1, 1}
+            else if (mode == M_NEAREST) d.r32 = 6;
+        }
     }
     if (d.r32) {
         d.point_kind = PK_NONE;

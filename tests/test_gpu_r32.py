@@ -1,4 +1,4 @@
-"""GPU: the streaming BILINEAR kernel for the exact ratio 3 : 2 with uint8 outputs (vpp_bilinear_r32_kernel: the whole 2x2 blend as
+"""GPU: the streaming kernel for the exact ratios 3 : 2 and 2 : 1 with uint8 outputs (vpp_bilinear_r32_kernel: the whole 2x2 blend as
 v_dot4 on source dwords with compile-time byte weights, no LDS) against the oracle, bit for bit: every flavour it takes, partial tile
 columns / rows, odd and even partial runs of the merged-output exchange, crops, batches; requests it cannot take fall back."""
 import os
@@ -21,6 +21,8 @@ def check(vpp, oracle, y, uv, w, dst, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0),
     if not any(k.startswith("TSVPP_") for k in os.environ):
         k = V.describe(fp, w, y.shape[0], pitch=y.shape[1], n_frames=n)["kernel"]
         assert k.startswith("vpp_bilinear_r32_kernel") == r32, (k, w, y.shape, dst, crop)
+        if r32:
+            assert k.endswith("2:1>" if 2 * dst[0] == (crop[2] - crop[0] or w) else "3:2>"), k
     ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
     got = vpp.Convert(ty, tuv, fp, width=w) if n == 1 else vpp.convert_batch([ty] * n, [tuv] * n, fp, width=w)
     torch.cuda.synchronize()
@@ -81,4 +83,38 @@ def test_r32_fuzz(vpp, oracle, chunk):
         pitch = (w + 3) // 4 * 4 + 4 * int(rng.integers(0, 4))
         fourcc, planes = [(RGB24, 0), (RGB24, 1), (BGR24, 0), (BGR24, 1), (NV12, 1), (Y800, 1), (UYVY, 1), (YUV444, 1)][int(rng.integers(0, 8))]
         y, uv = synth_nv12(w, h, seed=8000 + 100 * chunk + k, pitch=pitch)
+        check(vpp, oracle, y, uv, w, (dw, dh), fourcc=fourcc, planes=planes, n=int(rng.choice([1, 1, 2])), rt=int(rng.choice([NEAREST, BILINEAR, AREA])))
+
+
+@pytest.mark.parametrize("src,pitch", [((3840, 2160), 3840), ((1920, 1080), 2048), ((64, 32), 64), ((1936, 1096), 1952),
+                                       ((592, 88), 592),     # 37 threads per row: a partial run of 5 lanes
+                                       ((608, 88), 612)])    # 38 threads per row: a partial run of 6 lanes
+@pytest.mark.parametrize("fourcc,planes", [(RGB24, 0), (BGR24, 1), (NV12, 1), (Y800, 1)])
+@pytest.mark.parametrize("rt", [BILINEAR, AREA, NEAREST])
+def test_r21_sizes_and_flavours(vpp, oracle, src, pitch, fourcc, planes, rt):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + fourcc + planes + rt + 1, pitch=pitch)
+    big_planar_bilinear = rt == BILINEAR and fourcc == RGB24 and planes == 0 and src[0] * src[1] // 4 >= 1500000   # stays on the LDS kernel
+    check(vpp, oracle, y, uv, src[0], (src[0] // 2, src[1] // 2), fourcc=fourcc, planes=planes, rt=rt, r32=not big_planar_bilinear)
+
+
+def test_r21_batches_crops_two_pass(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=41, pitch=2048)
+    for rt in (BILINEAR, AREA, NEAREST):
+        check(vpp, oracle, y, uv, 1920, (960, 540), fourcc=RGB24, planes=1, n=64, rt=rt)
+        check(vpp, oracle, y, uv, 1920, (640, 360), crop=(8, 6, 1288, 726), rt=rt)
+        check(vpp, oracle, y, uv, 1920, (640, 360), crop=(10, 6, 1290, 726), rt=rt, r32=False)   # misaligned origin
+    for fcc in (UYVY, YUV444):
+        check(vpp, oracle, y, uv, 1920, (960, 540), fourcc=fcc, planes=1)
+    check(vpp, oracle, y, uv, 1920, (960, 540), norm=True, r32=False)
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_r21_fuzz(vpp, oracle, chunk):
+    rng = np.random.default_rng(2100 + chunk)
+    for k in range(24):
+        dw, dh = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 4
+        w, h = dw * 2, dh * 2
+        pitch = w + 4 * int(rng.integers(0, 4))
+        fourcc, planes = [(RGB24, 0), (RGB24, 1), (BGR24, 0), (BGR24, 1), (NV12, 1), (Y800, 1), (UYVY, 1), (YUV444, 1)][int(rng.integers(0, 8))]
+        y, uv = synth_nv12(w, h, seed=9000 + 100 * chunk + k, pitch=pitch)
         check(vpp, oracle, y, uv, w, (dw, dh), fourcc=fourcc, planes=planes, n=int(rng.choice([1, 1, 2])), rt=int(rng.choice([NEAREST, BILINEAR, AREA])))

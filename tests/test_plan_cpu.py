@@ -27,14 +27,21 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     # widths that do not fill 256-wide tiles stay on 128; uint8 outputs (VALU-bound) keep the tall thread tiles
     assert plan((3840, 2160), (1920, 1080), B)["shape"] == "32x8" and plan((3840, 2160), (1920, 1080), B)["geo"] == 0
     # ... and, with dyadic weights and 16-byte pitches, read host-built geometry tables on 64-wide workgroups (scalar row records)
-    p = plan((3840, 2160), (1920, 1080), B, norm=False)
-    assert (p["kernel"], p["shape"], p["rpt"], p["geo"]) == ("vpp_bilinear_kernel<bilinear,OUT>", "64x4", 2, 1)
-    p = plan((3840, 2160), (1920, 1080), B, norm=False, pitch=3848)     # pitch % 16 != 0: rows of differing misalignment
-    assert (p["shape"], p["rpt"], p["geo"]) == ("32x8", 2, 0)
-    # uint8 outputs at exactly 3 : 2 (1080p -> 720p): the streaming kernel without LDS -- BILINEAR, AREA and NEAREST; fp32 and BICUBIC not
+    p = plan((1920, 1080), (1536, 864), B, norm=False)                  # 5 : 4
+    assert (p["kernel"], p["shape"], p["geo"]) == ("vpp_bilinear_kernel<bilinear,OUT>", "64x4", 1)
+    p = plan((1920, 1080), (1536, 864), B, norm=False, pitch=1928)      # pitch % 16 != 0: rows of differing misalignment
+    assert (p["shape"], p["geo"]) == ("32x8", 0)
+    # uint8 outputs at exactly 3 : 2 (1080p -> 720p) or 2 : 1 (4K -> 1080p): the streaming kernel without LDS -- BILINEAR, AREA and
+    # NEAREST; fp32 and BICUBIC not
     for rt, kind in ((B, "bilinear"), (A, "area"), (N, "nearest")):
         p = plan((1920, 1080), (1280, 720), rt, norm=False, pitch=2048)
-        assert (p["kernel"], p["shape"], p["tiles"], p["geo"]) == ("vpp_bilinear_r32_kernel<OUT,%s>" % kind, "64x4", "3x45", 0)
+        assert (p["kernel"], p["shape"], p["tiles"], p["geo"]) == ("vpp_bilinear_r32_kernel<OUT,%s,3:2>" % kind, "64x4", "3x45", 0)
+        p = plan((3840, 2160), (1920, 1080), rt, norm=False, planes=1)
+        assert (p["kernel"], p["shape"], p["tiles"]) == ("vpp_bilinear_r32_kernel<OUT,%s,2:1>" % kind, "64x4", "4x68")
+    # ... except BILINEAR 2 : 1 with large planar outputs, where the LDS kernel with geometry tables measured faster
+    assert plan((3840, 2160), (1920, 1080), B, norm=False)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"
+    assert plan((1920, 1080), (960, 540), B, norm=False)["kernel"] == "vpp_bilinear_r32_kernel<OUT,bilinear,2:1>"
+    assert plan((3840, 2160), (1920, 1080), B)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"
     assert plan((1920, 1080), (1280, 720), C, norm=False)["kernel"] == "vpp_bicubic_int_kernel<OUT>"
     assert plan((1920, 1080), (1280, 720), B, norm=False, pitch=1922)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"   # planes not dword-aligned
     assert plan((1926, 1080), (1284, 720), B, norm=False)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"               # width 8 k + 4
