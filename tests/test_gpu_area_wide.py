@@ -1,6 +1,8 @@
 """GPU: AREA down-scales with 9-32 horizontal taps (ratios 8.5 .. 31: 1080p -> 224 x 224, 4K -> 224 x 224, thumbnails) against the
 oracle, bit for bit: the column-per-lane kernels (vpp_area_cols_lds_kernel with the host-built divisor table up to 12 taps,
 vpp_area_cols_kernel<4..8, 8> beyond), which replaced the generic gather path (0.05 of the roofline) for these requests."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -37,8 +39,9 @@ def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 
 ])
 def test_wide_ratios(vpp, oracle, src, dst, kernel):
     import tensor_stream as ts
-    p = ts.describe(ts.FrameParameters(width=dst[0], height=dst[1], resize_type=AREA, normalization=True, planes_pos=0), src[0], src[1])
-    assert p["kernel"].startswith(kernel), p
+    if not any(k.startswith("TSVPP_") for k in os.environ):   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
+        p = ts.describe(ts.FrameParameters(width=dst[0], height=dst[1], resize_type=AREA, normalization=True, planes_pos=0), src[0], src[1])
+        assert p["kernel"].startswith(kernel), p
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0])
     run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True)
     run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False)
