@@ -178,17 +178,21 @@ hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     const bool square = d.box_ry == d.box_rx;
     if (info) {
-        static const char *const names[2][5] = { { "vpp_area_box_kernel<4,0,OUT>", "vpp_area_box_kernel<5,0,OUT>", "vpp_area_box_kernel<6,0,OUT>",
-                                                   "vpp_area_box_kernel<7,0,OUT>", "vpp_area_box_kernel<8,0,OUT>" },
-                                                 { "vpp_area_box_kernel<4,1,OUT>", "vpp_area_box_kernel<5,1,OUT>", "vpp_area_box_kernel<6,1,OUT>",
-                                                   "vpp_area_box_kernel<7,1,OUT>", "vpp_area_box_kernel<8,1,OUT>" } };
-        if (d.box_rx < 4 || d.box_rx > 8) return hipErrorInvalidValue;
-        info->kernel = names[square ? 1 : 0][d.box_rx - 4];
+        static const char *const names[2][7] = { { "vpp_area_box_kernel<2,0,OUT>", "vpp_area_box_kernel<3,0,OUT>", "vpp_area_box_kernel<4,0,OUT>", "vpp_area_box_kernel<5,0,OUT>",
+                                                   "vpp_area_box_kernel<6,0,OUT>", "vpp_area_box_kernel<7,0,OUT>", "vpp_area_box_kernel<8,0,OUT>" },
+                                                 { "vpp_area_box_kernel<2,1,OUT>", "vpp_area_box_kernel<3,1,OUT>", "vpp_area_box_kernel<4,1,OUT>", "vpp_area_box_kernel<5,1,OUT>",
+                                                   "vpp_area_box_kernel<6,1,OUT>", "vpp_area_box_kernel<7,1,OUT>", "vpp_area_box_kernel<8,1,OUT>" } };
+        if (d.box_rx < 2 || d.box_rx > 8) return hipErrorInvalidValue;
+        info->kernel = names[square ? 1 : 0][d.box_rx - 2];
         info->grid = (int)grid.x;
         info->lds_bytes = 0;
         return hipSuccess;
     }
     switch (d.box_rx * 2 + (square ? 1 : 0)) {
+    case 4: return launch_box_rs<2, false>(out, d, t, grid, block, stream);
+    case 5: return launch_box_rs<2, true>(out, d, t, grid, block, stream);
+    case 6: return launch_box_rs<3, false>(out, d, t, grid, block, stream);
+    case 7: return launch_box_rs<3, true>(out, d, t, grid, block, stream);
     case 8: return launch_box_rs<4, false>(out, d, t, grid, block, stream);
     case 9: return launch_box_rs<4, true>(out, d, t, grid, block, stream);
     case 10: return launch_box_rs<5, false>(out, d, t, grid, block, stream);

@@ -1467,6 +1467,15 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.area_direct = 0;
     // integer horizontal ratio (one all-ones weight row), 4-byte aligned planes and pitches: the box kernel's contiguous runs
     d.area_box = (d.area_direct == 1 && d.area_box_pref && d.box_rx >= 4 && d.box_rx <= 8 && d.box_rx == d.rx && d.in_aligned4 && d.ry <= 8) ? 1 : 0;
+    // integer horizontal ratios 2 and 3 (1080p -> 960x540, 1080p -> 640x360, 4K -> 720p): below area_direct_min these went to the LDS
+    // kernel (measured against the round-1 direct kernel); the box kernel wins there too (profiles/r02_area_box23_ab.txt: 1080p -> 640x360
+    // fp32 0.602 -> 0.715, uint8 0.492 -> 0.666, 4K -> 720p uint8 merged 0.536 -> 0.711, 1080p -> 960x540 fp32 0.673 -> 0.707).
+    // TSVPP_AREA_BOX=4 keeps it to ratios >= 4.
+    if (!d.area_box && d.area_box_pref && d.area_box_pref != 4 && mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && (d.box_rx == 2 || d.box_rx == 3) &&
+        d.box_rx == d.rx && d.in_aligned4 && d.ry <= 8 && d.yr >= 2.0f) {
+        d.area_direct = 1;
+        d.area_box = 1;
+    }
     // measured (round 2, profiles/r02_area_cols_ab.txt; TSVPP_AREA_COLS=0/1/2, TSVPP_AREA_COLS_ROWS=8/32): the column-per-lane
     // kernel wins from 5 horizontal taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 %, 4K -> 608x342 +11 %, and with 8-row tiles
     // (four times the waves) also at 9-12 taps: 1080p -> 224^2 +11 % -- and is even at 2-4 taps

@@ -60,8 +60,9 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (768, 432), A, "vpp_area_box_kernel<5,1"),            # 5 x 5
     ((1920, 1080), (480, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 4 x 3: the vertical ratio is below the direct threshold
     ((1920, 1080), (1280, 720), A, "vpp_area_dyadic_kernel<1,2"),       # 1.5: dyadic weights, LDS
-    ((1920, 1080), (960, 540), A, "vpp_area_dyadic_kernel<1,2"),        # 2: LDS kernel below 3.5
-    ((1920, 1080), (640, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 3
+    ((1920, 1080), (960, 540), A, "vpp_area_box_kernel<2,1"),           # 2 x 2 and 3 x 3: the box kernel as well (round 2: measured faster than the LDS kernel)
+    ((1920, 1080), (640, 360), A, "vpp_area_box_kernel<3,1"),
+    ((1920, 1080), (960, 360), A, "vpp_area_box_kernel<2,0"),           # 2 x 3
     ((2560, 1440), (1920, 1080), A, "vpp_areaf_kernel<2,2"),            # 4/3: float weights, 2 x 2 taps
     ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
@@ -98,10 +99,10 @@ def test_small_outputs_keep_two_row_thread_tiles():
     # (pitch 1922: planes not dword-aligned, so neither the streaming 3 : 2 kernel nor the geometry tables apply -- the plain LDS kernel)
     assert plan((1920, 1080), (1280, 720), B, n_frames=8, norm=False, pitch=1922)["rpt"] == 1    # 10 x 23 x 8 tiles of 128 x 32 = 1840
     assert plan((1920, 1080), (1280, 720), B, n_frames=64, norm=False, pitch=1922)["rpt"] == 2   # 14720 >= 12288
-    assert plan((1920, 1080), (960, 540), B, n_frames=64, norm=False)["rpt"] == 1    # 8704
+    assert plan((1920, 1080), (960, 540), B, n_frames=64, norm=False, pitch=1922)["rpt"] == 1    # 8704
     # dyadic AREA: most resident workgroups first; since round 2 the LDS-DMA layout is as compact as the register-staged one
     # (any number of chunks per row), so it wins the tie: 1080p -> 960x540 two-row tiles, 21 KiB, LDS-DMA
-    p = plan((1920, 1080), (960, 540), A, n_frames=64)
+    p = plan((1920, 1080), (960, 540), A, n_frames=64, pitch=1922)       # (pitch 1922: not dword-aligned, so not the box kernel)
     assert (p["rpt"], p["dma"]) == (1, 1) and p["lds"] < 22 * 1024
     p = plan((1920, 1080), (1536, 864), A, n_frames=64)                  # >= 5 per CU either way: taller tile, LDS-DMA
     assert (p["rpt"], p["dma"]) == (2, 1)
