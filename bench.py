@@ -7,11 +7,12 @@ crop+resize+colour kernel converting `--batch` (default 64) independent frames
 BILINEAR -> BGR24 PLANAR fp32 (normalised).  Inputs are resident in HBM before the timed region;
 the batch rotates over enough buffer sets that the working set is > 512 MiB (Infinity Cache is 256 MiB).
 
-Timing: W warm-up steps, then the timed region of EXACTLY K steps -- barrier +
-torch.cuda.synchronize() on both sides, HIP events on the launch stream inside -- is run `--repeats`
-times back to back (default max(5, ceil(400 / K)): at least 200 timed iterations, with the ~25 ms clock ramp in the slower tail) and the MEDIAN region is reported
-(`ms_per_step` = median wall / K; every repeat is listed in `timing.repeats_ms_per_step`: the first regions of a
-short run are slower, the device needs ~20 ms of continuous work to settle its clocks).  Max over ranks per repeat.
+Timing: W warm-up steps plus a TIME-BASED warm-up (untimed steps until the device has worked for
+`--warmup-ms`, default 40 ms: it needs ~25 ms of continuous work to settle its clocks), then the timed region of
+EXACTLY K steps -- barrier + torch.cuda.synchronize() on both sides, HIP events on the launch stream inside -- is
+run `--repeats` times back to back (default max(5, ceil(400 / K)): at least 200 timed iterations) and the MEDIAN
+region is reported (`ms_per_step` = median wall / K; every repeat is listed in `timing.repeats_ms_per_step`, with
+`timing.total_timed_steps` and the mean over all of them).  Max over ranks per repeat.
 
 Prints ONE JSON line (rank 0).  N>1: one rank per GPU, launched either by torch.distributed.run (RANK /
 WORLD_SIZE in the environment) or by this script itself when `--gpus N` is given without such an environment
@@ -227,6 +228,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the NEAREST/BICUBIC/AREA side measurements of the headline")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--warmup-ms", type=float, default=40.0, help="time-based warm-up after the --warmup steps: untimed steps until the device has worked this long (clock ramp)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to the CPUs local to its GPU")
     return ap.parse_args(argv)
 
 
@@ -308,127 +311,164 @@ class StubEngine:
         pass
 
 
+class GpuWork:
+    """One workload resident in HBM: `sets` rotating buffer sets of B synthetic frames (distinct per frame / set / rank)
+    and the prebuilt batch descriptors (a step is then one C-ABI call per `per_call` frames)."""
+
+    def __init__(self, eng, spec, B, sets, seed, alias=0, per_call=0):
+        torch, ts, vpp = eng.torch, eng.ts, eng.vpp
+        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+        self.spec, self.B, self.torch = spec, B, torch
+        self.fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=RESIZE[rt],
+                                     pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
+        vpp.prepare(self.fp, src_w, src_h, n_frames=B)  # tables + scratch for this batch size: the timed region allocates nothing
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        self.sets = []
+        for _ in range(sets):
+            ys = torch.randint(0, 256, (B, src_h, pitch), dtype=torch.uint8, device="cuda", generator=g)
+            uvs = torch.randint(0, 256, (B, src_h // 2, pitch), dtype=torch.uint8, device="cuda", generator=g)
+            out = vpp._alloc(self.fp.parameters, src_w, src_h, B)
+            if alias & 1:   # diagnostic: every frame of the set reads frame 0 (reads stay in L2 / Infinity Cache)
+                ys, uvs = ys[:1].expand(B, -1, -1), uvs[:1].expand(B, -1, -1)
+            if alias & 2:   # diagnostic: every frame writes frame 0's buffer (writes combine in L2)
+                out = out[:1].expand(B, *([-1] * (out.dim() - 1)))
+            self.sets.append((ys, uvs, out))
+        self.ws_mib = sum(a.numel() * a.element_size() for s in self.sets for a in s) / 2**20
+        # descriptor arrays are built once per buffer set; a step is then a single C-ABI call
+        F = per_call if 0 < per_call < B else B
+        self.batches = [[vpp.make_batch(ys[k:k + F], uvs[k:k + F], self.fp, out=out[k:k + F], width=src_w) for k in range(0, B, F)]
+                        for (ys, uvs, out) in self.sets]
+        self.launches_per_step = ((F + 63) // 64) * (B // F) + ((B % F + 63) // 64)
+        self.frames_per_launch = B / self.launches_per_step
+        self.vpp = vpp
+
+    def parity(self, O):
+        """Frame 1 of set 0 through the HIP path against the oracle, bit for bit."""
+        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = self.spec
+        ys, uvs, out = self.sets[0]
+        self.vpp.convert_batch(ys[:2], uvs[:2], self.fp, out=out[:2], width=src_w)
+        self.torch.cuda.synchronize()
+        ref, _, _ = O.convert(ys[1].cpu().numpy(), uvs[1].cpu().numpy(), crop=crop, dst=dst, resize_type=RESIZE[rt],
+                              fourcc=FOURCC[fcc], planes=PLANES[planes], normalization=norm, nthreads=min(16, O.host_cores()), width=src_w)
+        got = out[1].cpu().numpy().ravel()
+        return np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+
+    def issue(self, i, stream):
+        for b in self.batches[i % len(self.batches)]:
+            self.vpp.run_batch(b, stream)
+
+
 class GpuEngine:
     def __init__(self, args, spec, rank, dev, dist):
         import torch
         import tensor_stream as ts
         from tensor_stream import parallel
-        self.torch, self.ts, self.dev = torch, ts, dev
+        self.torch, self.ts, self.dev, self.rank, self.args = torch, ts, dev, rank, args
         src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
         self.spec = spec
         self.vpp = ts.VideoProcessor(device=dev, max_consumers=8)
         # the one collective of the path: rank 0's colour coefficient block -> every rank (RCCL over xGMI)
-        parallel.broadcast_coeffs(self.vpp, dist)
-        self.fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=RESIZE[rt],
-                                     pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
-        self.vpp.prepare(self.fp, src_w, src_h, n_frames=args.batch)  # tables + scratch for this batch size: the timed region allocates nothing
+        self.coeffs = parallel.broadcast_coeffs(self.vpp, dist)
+        self.coeff_broadcast = parallel.last_broadcast_info()
         B = args.batch
-        # synthetic full-range NV12, distinct per frame / set / rank
-        g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        self.sets = []
-        for _ in range(args.sets):
-            ys = torch.randint(0, 256, (B, src_h, pitch), dtype=torch.uint8, device="cuda", generator=g)
-            uvs = torch.randint(0, 256, (B, src_h // 2, pitch), dtype=torch.uint8, device="cuda", generator=g)
-            out = self.vpp._alloc(self.fp.parameters, src_w, src_h, B)
-            if args.alias & 1:   # diagnostic: every frame of the set reads frame 0 (reads stay in L2 / Infinity Cache)
-                ys, uvs = ys[:1].expand(B, -1, -1), uvs[:1].expand(B, -1, -1)
-            if args.alias & 2:   # diagnostic: every frame writes frame 0's buffer (writes combine in L2)
-                out = out[:1].expand(B, *([-1] * (out.dim() - 1)))
-            self.sets.append((ys, uvs, out))
-        self.ws_mib = sum(a.numel() * a.element_size() for s in self.sets for a in s) / 2**20
+        self.work = GpuWork(self, spec, B, args.sets, 1234 + rank, alias=args.alias, per_call=args.per_call)
+        self.fp = self.work.fp
+        self.ws_mib = self.work.ws_mib
+        self.launches_per_step = self.work.launches_per_step
+        self.frames_per_launch = self.work.frames_per_launch
 
         self.parity = "skipped"
         if not args.no_parity and rank == 0:
             from oracle import oracle as O
-            ys, uvs, out = self.sets[0]
-            self.vpp.convert_batch(ys[:2], uvs[:2], self.fp, out=out[:2], width=src_w)
-            torch.cuda.synchronize()
-            ref, _, _ = O.convert(ys[1].cpu().numpy(), uvs[1].cpu().numpy(), crop=crop, dst=dst, resize_type=RESIZE[rt],
-                                  fourcc=FOURCC[fcc], planes=PLANES[planes], normalization=norm, nthreads=min(16, O.host_cores()), width=src_w)
-            got = out[1].cpu().numpy().ravel()
-            same = np.array_equal(got.view(np.uint8), ref.view(np.uint8))
-            self.parity = "bit-exact vs oracle" if same else "MISMATCH vs oracle"
+            same = self.work.parity(O)
+            self.parity = "bit-exact vs oracle (1 frame of the batch, full size)" if same else "MISMATCH vs oracle"
             if rt == "BICUBIC":  # VERDICT r01 weak #3: the oracle's pow(w,2)/pow(w,3) are the exact square / correctly rounded cube
                 self.parity += " (BICUBIC at non-dyadic weights is oracle-defined: the reference's pow() is library-dependent)"
             if not same:
                 print(json.dumps({"error": "parity gate failed", "workload": args.workload}), flush=True)
                 sys.exit(2)
 
-        # descriptor arrays are built once per buffer set; a step is then a single C-ABI call
-        F = args.per_call if 0 < args.per_call < B else B
-        self.batches = [[self.vpp.make_batch(ys[k:k + F], uvs[k:k + F], self.fp, out=out[k:k + F], width=src_w) for k in range(0, B, F)]
-                        for (ys, uvs, out) in self.sets]
-        self.launches_per_step = ((F + 63) // 64) * (B // F) + ((B % F + 63) // 64)
-        self.frames_per_launch = B / self.launches_per_step
         self.cur_stream = torch.cuda.current_stream(dev).cuda_stream
         self.graphs = []
         if args.graph:  # one graph per buffer set, captured on a side stream, replayed on the current one
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):
-                for i in range(len(self.batches)):
-                    self._issue(i, side.cuda_stream)
+                for i in range(len(self.work.batches)):
+                    self.work.issue(i, side.cuda_stream)
             torch.cuda.synchronize()
-            for i in range(len(self.batches)):
+            for i in range(len(self.work.batches)):
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=side):
-                    self._issue(i, side.cuda_stream)
+                    self.work.issue(i, side.cuda_stream)
                 self.graphs.append(gr)
 
-    def _issue(self, i, stream):
-        for b in self.batches[i % len(self.batches)]:
-            self.vpp.run_batch(b, stream)
+    def kernel_name(self):
+        """The kernel the timed launches dispatch (host-side dry run of the same selection: tsvpp_describe)."""
+        src_w, src_h, pitch = self.spec[0], self.spec[1], self.spec[2]
+        try:
+            dsc = self.ts.vpp.describe(self.fp, src_w, src_h, pitch=pitch, n_frames=int(min(self.args.batch, 64)))
+            return "tsvpp::" + str(dsc.get("kernel", "?"))
+        except Exception as e:
+            return f"tsvpp::? ({type(e).__name__}: {e})"
 
     def step(self, i):
         if self.graphs:
             self.graphs[i % len(self.graphs)].replay()
         else:
-            self._issue(i, self.cur_stream)
+            self.work.issue(i, self.cur_stream)
 
     def sync(self):
         self.torch.cuda.synchronize()
 
-    def timed(self, steps, first):
+    def timed(self, steps, first, work=None):
         """K steps between two HIP events on torch's current stream == the stream convert_batch launches on.
         Returns (device ms between the events, host seconds spent issuing)."""
         torch = self.torch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for i in range(steps):
-            self.step(first + i)
+        if work is None:
+            for i in range(steps):
+                self.step(first + i)
+        else:
+            for i in range(steps):
+                work.issue(first + i, self.cur_stream)
         ev1.record()
         host_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1), host_issue
 
-    def other_resize_types(self, bytes_per_frame, B):
-        """BASELINE.json's metric names no resize type (SURVEY.md 8d: "report all four"): the timed region is BILINEAR;
-        the other three on the same buffers, 20 launches each, outside the timed region."""
-        torch, ts = self.torch, self.ts
-        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = self.spec
-        others = {}
-        for name in ("NEAREST", "BICUBIC", "AREA"):
-            try:
-                fp2 = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=RESIZE[name],
-                                         pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
-                self.vpp.prepare(fp2, src_w, src_h)
-                bs = [self.vpp.make_batch(ys, uvs, fp2, out=out, width=src_w) for (ys, uvs, out) in self.sets]
-                for i in range(3):
-                    self.vpp.run_batch(bs[i % len(bs)], self.cur_stream)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for i in range(20):
-                    self.vpp.run_batch(bs[i % len(bs)], self.cur_stream)
-                b.record()
-                torch.cuda.synchronize()
-                ms = a.elapsed_time(b) / 20
-                others[name] = {"frames_per_s": round(B / (ms * 1e-3), 1), "hbm_frac": round(bytes_per_frame * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            except Exception as e:  # a side leg must never swallow the line
-                others[name] = {"error": f"{type(e).__name__}: {e}"}
-        return others
+    def side_work(self, spec, sets=2):
+        """A second workload on the same context (other resize types of the headline, the 4K configurations): its own buffers."""
+        return GpuWork(self, spec, self.args.batch, sets, 4321 + self.rank)
 
     def close(self):
         self.vpp.Close()
+
+
+def pin_to_gpu_numa(dev):
+    """Best effort: restrict this rank to the CPUs local to its GPU's PCIe root (the >= 7.5x target at 8 GPUs dies on host
+    launch overhead, nothing else).  Returns a short description for the JSON line; never raises."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(getattr(p, "pci_device_id", 0)))
+        path = f"/sys/bus/pci/devices/{bdf.lower()}/local_cpulist"
+        cpus = set()
+        for part in open(path).read().strip().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        if not want:
+            return f"{bdf}: local CPUs outside this process's cpuset (left unpinned, {len(allowed)} CPUs)"
+        if want != allowed:
+            os.sched_setaffinity(0, want)
+        return f"{bdf}: {len(want)} local CPUs of {len(allowed)} allowed"
+    except Exception as e:
+        return f"unpinned ({type(e).__name__}: {e})"
 
 
 def run(args):
@@ -440,7 +480,10 @@ def run(args):
     src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
     dist = None
     out_fd = None
-    if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on one GPU
+    backend = None
+    # world == 1 still takes the collective path under torch.distributed.run (`--nproc-per-node=1`) or TSVPP_BENCH_FORCE_DIST=1:
+    # the RCCL plumbing is exercised on a one-GPU box (tests/test_bench_gpu.py) before an 8-GPU node ever sees it
+    if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1" or "TORCHELASTIC_RUN_ID" in os.environ:
         # RCCL prints a version banner on stdout: keep stdout for the ONE JSON line (everything else goes to stderr)
         sys.stdout.flush()
         out_fd = os.dup(1)
@@ -449,22 +492,31 @@ def run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if stub:
+            backend = "gloo"
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             import torch
+            backend = "nccl"
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    affinity = None
     if stub:
         eng = StubEngine(args, spec, rank)
     else:
         import torch
         dev = local if dist is not None else 0
         torch.cuda.set_device(dev)
+        if dist is not None and not args.no_pin:
+            affinity = pin_to_gpu_numa(dev)
         eng = GpuEngine(args, spec, rank, dev, dist)
 
     B = args.batch
-    chans = {0: 1.0, 3: 1.5, 4: 2.0}.get(FOURCC[fcc], 3.0)
-    bytes_per_frame = algorithmic_bytes(src_w, src_h, crop, dst, norm or fcc == "HSV", chans, luma_only=(fcc == "Y800"))
+
+    def bytes_of(sp):
+        chans = {0: 1.0, 3: 1.5, 4: 2.0}.get(FOURCC[sp[6]], 3.0)
+        return algorithmic_bytes(sp[0], sp[1], sp[3], sp[4], sp[8] or sp[6] == "HSV", chans, luma_only=(sp[6] == "Y800"))
+
+    bytes_per_frame = bytes_of(spec)
 
     def barrier():
         if dist is not None:
@@ -478,42 +530,98 @@ def run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
-    for i in range(args.warmup):
-        eng.step(i)
-    reps = []
-    first = args.warmup
-    # The device needs ~25 ms of continuous work to settle its clocks (profiles/r02_bench_driver_cmd.json, first version: regions
-    # of 20 steps ran 0.167, 0.182, 0.163, 0.158, 0.156, 0.150, 0.148, 0.148, 0.146, 0.146 ms per step).  400 timed iterations put the
-    # ramp into the slower tail of the repeats instead of at their median; the reported region is still exactly --steps steps.
-    n_rep = args.repeats if args.repeats > 0 else max(5, -(-400 // max(1, args.steps)))
-    for _ in range(n_rep):
+    def gather(val):
+        """One float per rank -> list (rank order) on every rank."""
+        if dist is None:
+            return [val]
+        import torch
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if stub else "cuda")
+        t[rank] = val
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.tolist()
+
+    def region(steps, first, work=None):
+        """One timed region of exactly `steps` steps: barrier + synchronize on both sides, max over ranks."""
         barrier()
         eng.sync()
         t0 = time.perf_counter()
-        dev_ms, host_issue = eng.timed(args.steps, first)  # ends with a device synchronize
+        dev_ms, host_issue = eng.timed(steps, first, work) if work is not None else eng.timed(steps, first)  # ends with a device synchronize
         barrier()
         wall = time.perf_counter() - t0
+        mine = (wall, dev_ms, host_issue)
+        return tuple(reduce_max(list(mine))), mine
+
+    for i in range(args.warmup):
+        eng.step(i)
+    first = args.warmup
+    # Time-based warm-up: the device needs ~25 ms of continuous work to settle its clocks (profiles/r02_bench_driver_cmd.json, first
+    # version: regions of 20 steps ran 0.167, 0.182, 0.163, 0.158, 0.156, 0.150, 0.148 ... ms per step).  Untimed steps until
+    # `--warmup-ms` of device work have passed, so that no timed region sits on the ramp.
+    extra = 0
+    if args.warmup_ms > 0:
+        t_w = time.perf_counter()
+        eng.sync()
+        while (time.perf_counter() - t_w) * 1e3 < args.warmup_ms and extra < 100000:
+            for _ in range(8):
+                eng.step(first)
+                first += 1
+                extra += 1
+            eng.sync()
+    reps, mine_reps = [], []
+    n_rep = args.repeats if args.repeats > 0 else max(5, -(-400 // max(1, args.steps)))
+    for _ in range(n_rep):
+        r, mine = region(args.steps, first)
         first += args.steps
-        wall, dev_ms, host_issue = reduce_max([wall, dev_ms, host_issue])
-        reps.append((wall, dev_ms, host_issue))
+        reps.append(r)
+        mine_reps.append(mine)
     # per-rank rate of the median repeat (min / max over ranks), N > 1 only
     order = sorted(range(len(reps)), key=lambda k: reps[k][0])
     med = order[len(order) // 2]
     wall, dev_ms, host_issue = reps[med]
     per_rank = None
     if dist is not None:
-        import torch
-        mine = torch.tensor([B * args.steps / wall], dtype=torch.float64, device="cpu" if stub else "cuda")
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        per_rank = {"min_frames_per_s": round(lo.item(), 1), "max_frames_per_s": round(hi.item(), 1)}
+        rates = gather(B * args.steps / mine_reps[med][0])
+        issue = gather(mine_reps[med][2] * 1e3 / args.steps)
+        per_rank = {"min_frames_per_s": round(min(rates), 1), "max_frames_per_s": round(max(rates), 1),
+                    "frames_per_s": [round(x, 1) for x in rates], "host_issue_ms_per_step": [round(x, 4) for x in issue],
+                    "backend": backend, "rank0_affinity": affinity}
+
+    # Side measurements (outside the timed region, every rank takes part, same barrier / max-over-ranks bracket): the
+    # headline's other three resize types (BASELINE.json's metric names none: SURVEY.md 8d "report all four") and the 4K
+    # configurations C4 / C5 (north_star: "1080p and 4K ... at 1/2/4/8 GPUs").
+    def side(sp, steps=20):
+        try:
+            w = eng.side_work(sp)
+            for i in range(3):
+                w.issue(i, eng.cur_stream)
+            (sw, sdev, _), _ = region(steps, 0, w)
+            bpf = bytes_of(sp)
+            ms = sdev / (steps * w.launches_per_step)
+            r = {"frames_per_s": round(B * steps * world / sw, 1), "avg_launch_ms": round(ms, 5),
+                 "hbm_frac": round(bpf * w.frames_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del w
+            return r
+        except Exception as e:  # a side leg must never swallow the line
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    others, other_wl = None, None
+    if not stub and name == "headline" and not args.resize and not args.no_others:
+        others = {}
+        for rname in ("NEAREST", "BICUBIC", "AREA"):
+            sp = list(spec)
+            sp[5] = rname
+            others[rname] = side(tuple(sp))
+        other_wl = {}
+        for wl in ("c4", "c5"):
+            other_wl[wl] = side(WORKLOADS[wl])
 
     if rank == 0:
         frames = B * args.steps * world
         kernel_ms = dev_ms / (args.steps * eng.launches_per_step)  # avg launch duration from HIP events
         fpl = eng.frames_per_launch
         achieved = bytes_per_frame * fpl / (kernel_ms * 1e-3) / 1e9
+        total_steps = args.steps * len(reps)
+        mean_wall = sum(r[0] for r in reps) / total_steps
         res = {
             "metric": metric_name(name, args.resize),
             "value": round(frames / wall, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -525,15 +633,20 @@ def run(args):
                        "buffer_sets": args.sets, "working_set_MiB": round(eng.ws_mib, 1), "sharding": f"frames/{world} ranks, no data collective",
                        "parity": eng.parity},
             "timing": {"repeats": len(reps), "reported": "median repeat (max over ranks per repeat)",
+                       "total_timed_steps": total_steps, "mean_ms_per_step": round(mean_wall * 1e3, 4),
+                       "max_ms_per_step": round(max(r[0] for r in reps) * 1e3 / args.steps, 4),
+                       "warmup_steps_total": args.warmup + extra, "warmup_ms": args.warmup_ms,
                        "repeats_ms_per_step": [round(r[0] * 1e3 / args.steps, 4) for r in reps],
                        "repeats_avg_launch_ms": [round(r[1] / (args.steps * eng.launches_per_step), 5) for r in reps]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "tsvpp::vpp_*_kernel (one fused launch)", "bytes_per_frame": bytes_per_frame,
+                         "kernel": eng.kernel_name() if not stub else "stub", "bytes_per_frame": bytes_per_frame,
                          "avg_launch_ms": round(kernel_ms, 5), "host_issue_ms_per_step": round(host_issue * 1e3 / args.steps, 4)},
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if dist is not None and not stub:
+            res["config"]["coeff_broadcast"] = eng.coeff_broadcast
         if args.alias:  # not a measurement of the path: the frames of a launch share buffers
             res["data"] = "DIAGNOSTIC: aliased buffers (--alias %d)" % args.alias
         try:  # graded on the ROI formula; touched_bytes explains fractions > 1 of the sparse samplers
@@ -546,13 +659,14 @@ def run(args):
             tr, why = lookup_traffic(name if not args.resize else (args.resize.lower() if name == "headline" else ""), fpl)
             res["roofline"]["traffic"] = tr
             res["roofline"]["traffic_source"] = why
+            if tr:  # the fraction of the peak on the bytes the launch actually moved (C3 / C4: below the ROI formula)
+                res["roofline"]["traffic_frac"] = round(tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as e:
             res["roofline"]["traffic_source"] = f"error: {type(e).__name__}: {e}"
-        if world == 1 and not stub and name == "headline" and not args.resize and not args.no_others:
-            try:
-                res["config"]["other_resize_types"] = eng.other_resize_types(bytes_per_frame, B)
-            except Exception as e:
-                res["config"]["other_resize_types"] = {"error": f"{type(e).__name__}: {e}"}
+        if others is not None:
+            res["config"]["other_resize_types"] = others
+        if other_wl is not None:
+            res["config"]["other_workloads"] = other_wl
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(spec, budget_s=args.cpu_budget, tight_pitch=args.tight_pitch)
@@ -565,6 +679,7 @@ def run(args):
             print(json.dumps(res), flush=True)
     eng.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     return 0
 

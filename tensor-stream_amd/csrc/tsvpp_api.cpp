@@ -440,7 +440,10 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
 // inner), so the kernel can load the divisor instead of spending one add per tap and lane on it.  Tables above 2^18 entries
 // are not built (the kernel then sums the weights itself).
 #pragma clang fp contract(off)
-int get_area_div(tsvpp_ctx *ctx, float xr, float yr, const AreaTable &tx, const AreaTable &ty, const float *&out) {
+// The table is an optimisation, never a requirement (the kernels sum the weights themselves when it is null): while `stream`
+// is capturing, or when the allocation fails, nothing is built or cached and the call still succeeds -- a first conversion
+// inside a hipGraph capture without tsvpp_prepare_batch runs the self-summing kernel instead of failing.
+int get_area_div(tsvpp_ctx *ctx, float xr, float yr, const AreaTable &tx, const AreaTable &ty, const float *&out, hipStream_t stream) {
     out = nullptr;
     uint32_t kx, ky;
     std::memcpy(&kx, &xr, 4);
@@ -454,6 +457,10 @@ int get_area_div(tsvpp_ctx *ctx, float xr, float yr, const AreaTable &tx, const 
     }
     float *dev = nullptr;
     if (tx.host4 && ty.host4 && (long)tx.rows * ty.rows <= (1L << 18)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
+        if (stream && hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) return TSVPP_OK; // no allocation, no synchronous copy during capture
         const int tx4 = 4 * tx.nk, ty4 = 4 * ty.nk;
         std::vector<float> tab((size_t)tx.rows * ty.rows);
         for (int jx = 0; jx < tx.rows; jx++) {
@@ -469,10 +476,14 @@ int get_area_div(tsvpp_ctx *ctx, float xr, float yr, const AreaTable &tx, const 
                 tab[(size_t)jx * ty.rows + iy] = div;
             }
         }
-        if (hipMalloc((void **)&dev, tab.size() * sizeof(float)) != hipSuccess) return TSVPP_ERROR;
+        if (hipMalloc((void **)&dev, tab.size() * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return TSVPP_OK; // out stays null
+        }
         if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
             (void)hipFree(dev);
-            return TSVPP_ERROR;
+            return TSVPP_OK;
         }
     }
     ctx->area_div[key] = dev;
@@ -679,11 +690,16 @@ int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int
     DeviceGuard guard(ctx);
     if (guard.status != TSVPP_OK) return guard.status;
     if (pl.mode == M_AREA_DOWN) {
-        AreaTable t;
-        sts = get_area_table(ctx, pl.xr, t);
+        AreaTable tx, ty;
+        sts = get_area_table(ctx, pl.xr, tx);
         if (sts != TSVPP_OK) return sts;
-        sts = get_area_table(ctx, pl.yr, t);
+        sts = get_area_table(ctx, pl.yr, ty);
         if (sts != TSVPP_OK) return sts;
+        if (!(tx.qdev && ty.qdev) && ctx->area_divtab) { // the float-weight kernels' divisor table: the same condition as in convert
+            const float *div = nullptr;
+            sts = get_area_div(ctx, pl.xr, pl.yr, tx, ty, div, (hipStream_t)stream);
+            if (sts != TSVPP_OK) return sts;
+        }
     }
     if (needs_scratch(pl) && n_frames > 0) { // the NV12 intermediate of UYVY / YUV444 behind a resize
         tsvpp_ctx::ScratchSlot *slot = scratch_slot(ctx, stream);
@@ -747,11 +763,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     }
     DeviceGuard guard(ctx);
     if (guard.status != TSVPP_OK) return guard.status;
-    char label[96];
-    if (ctx->markers)
+    char label[96] = "";
+    const bool markers = ctx->markers != 0; // read once: a concurrent tsvpp_enable_markers cannot push an unformatted label
+    if (markers)
         std::snprintf(label, sizeof(label), "tsvpp_convert n=%d %dx%d->%dx%d mode=%d fourcc=%d stream=%p", n, pl.src_w, pl.src_h, pl.dst_w, pl.dst_h,
                       (int)pl.mode, pl.fourcc, stream);
-    RangeGuard range(ctx->markers != 0, label);
+    RangeGuard range(markers, label);
 
     LaunchDesc d;
     fill_desc(ctx, pl, pitch_y, pitch_uv, d);
@@ -772,7 +789,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.paty4 = ty.dev4;
         d.nky = ty.nk;
         if (!(tx.qdev && ty.qdev) && ctx->area_divtab) { // float-weight kernels only
-            sts = get_area_div(ctx, pl.xr, pl.yr, tx, ty, d.area_div);
+            sts = get_area_div(ctx, pl.xr, pl.yr, tx, ty, d.area_div, (hipStream_t)stream);
             if (sts != TSVPP_OK) return sts;
         }
         if (tx.qdev && ty.qdev && dyadic_usable(pl.xr, pl.yr, tx.shift, ty.shift)) {
@@ -826,9 +843,6 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
             t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
         }
         d.n_frames = cnt;
-#ifdef TSVPP_DEBUG_LDS
-        if (const char *dp = std::getenv("TSVPP_DEBUG_PTR")) t.out[TSVPP_MAX_BATCH - 1] = (void *)std::strtoull(dp, nullptr, 0);
-#endif
         // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel); scratch frames are
         // 256-byte aligned.
         bool vec = true;

@@ -1,10 +1,15 @@
 // vpp_bilinear.hip -- the 2x2-tap kernel family (BILINEAR and the AREA up-scale variant; the headline kernel) in its own
-// translation unit, compiled with LDS accesses of unknown alignment split into byte reads (Makefile: -unaligned-access-mode
-// off for this file only).  Measured on MI355X: a ds_read_u16 / ds_read_b32 whose address is not naturally aligned is
+// translation unit, compiled with LDS accesses of unknown alignment split into byte reads (target feature `no-unaligned-access-mode`,
+// applied to this file's functions by the pragma below -- device pass only).  Measured on MI355X: a ds_read_u16 / ds_read_b32 whose address is not naturally aligned is
 // executed lane by lane (~64 cycles per wave instruction); at ratio 1.5 half of all tap addresses are odd, and the first
 // version of the integer thread tile, which read each horizontal tap pair as one 16-bit word, ran at 195 us per launch
 // whatever the output type (LDS-bound) against 154 us for the float tile (profiles/r02_bilinear_int_ab.txt).
 #include "vpp_device.h"
+
+// (device pass only: the host compiler does not know the feature)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-unaligned-access-mode"))), apply_to = function)
+#endif
 
 #include <algorithm>
 #include <cstring>
@@ -890,3 +895,7 @@ hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const Laun
 }
 
 } // namespace tsvpp
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif

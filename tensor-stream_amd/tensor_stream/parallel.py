@@ -8,6 +8,12 @@ Works with any torch.distributed backend -- the CPU tests run it on gloo with wo
 """
 import torch
 
+_LAST = {"collective": None}  # how the last coefficient broadcast travelled (bench.py reports it; the GPU tests assert on it)
+
+
+def last_broadcast_info():
+    return dict(_LAST)
+
 
 def shard_streams(n_streams, rank, world):
     """Stream s is served by rank s % world.  Returns this rank's stream ids."""
@@ -20,6 +26,7 @@ def broadcast_coeff_block(block, dist, device=None):
     """Broadcast rank 0's 8-float block; returns the received list.  `dist` is torch.distributed
     (initialised) or None for a single process."""
     if dist is None or not dist.is_initialized():
+        _LAST.update(collective=None, backend=None, device=None, world=1)
         return [float(x) for x in block]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -27,6 +34,7 @@ def broadcast_coeff_block(block, dist, device=None):
     if dist.get_rank() != 0:
         t.zero_()  # prove the values really travel
     dist.broadcast(t, src=0)
+    _LAST.update(collective="torch.distributed.broadcast", backend=str(dist.get_backend()), device=str(t.device), world=int(dist.get_world_size()))
     return [float(x) for x in t.cpu().tolist()]
 
 

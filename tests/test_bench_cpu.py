@@ -137,3 +137,17 @@ def test_stale_traffic_entries_are_dropped(tmp_path):
     for w in ("c2", "c5", "c3"):
         tr, why = bench.lookup_traffic(w, 64.0, str(p))
         assert tr is None and why
+
+
+def test_torchrun_world1_takes_the_collective_path_on_gloo():
+    """`torch.distributed.run --nproc-per-node=1 bench.py`: world size 1 still initialises the process group (the GPU twin of
+    this test, tests/test_bench_gpu.py, runs the same on the nccl backend) -- one line, per_rank present."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSVPP_BENCH_STUB"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    assert res["n_gpus"] == 1 and res["per_rank"]["backend"] == "gloo" and len(res["per_rank"]["host_issue_ms_per_step"]) == 1
+    assert res["timing"]["total_timed_steps"] == res["timing"]["repeats"] * 4

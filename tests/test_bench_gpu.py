@@ -1,0 +1,70 @@
+"""GPU: the RCCL ("nccl" backend) leg of bench.py on ONE GPU -- the path the driver's 2/4/8-GPU runs take
+(`python -m torch.distributed.run ... bench.py --gpus N`), exercised at world size 1 so that the first 8-GPU run
+cannot die on plumbing (round 1 lost its whole line to a one-line bug on an unexercised leg).
+Reference model: one instance per GPU, reference src/Wrappers/WrapperPython.cpp:18-29, README.md:193-196."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TSVPP_BENCH_STUB",
+                                                           "TORCHELASTIC_RUN_ID", "TSVPP_BENCH_FORCE_DIST")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra)
+    return env
+
+
+def _check(p):
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly ONE line (RCCL's banner belongs on stderr): {p.stdout[-3000:]}"
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["parity"].startswith("bit-exact")
+    pr = res["per_rank"]
+    assert pr["backend"] == "nccl" and len(pr["frames_per_s"]) == 1 and len(pr["host_issue_ms_per_step"]) == 1
+    assert pr["min_frames_per_s"] <= pr["max_frames_per_s"]
+    cb = res["config"]["coeff_broadcast"]  # the path's one collective really went through RCCL on a device tensor
+    assert cb["collective"] == "torch.distributed.broadcast" and cb["backend"] == "nccl" and cb["device"].startswith("cuda") and cb["world"] == 1
+    rf = res["roofline"]
+    assert rf["kernel"].startswith("tsvpp::vpp_bilinear_kernel") and "*" not in rf["kernel"]
+    assert 0.3 < rf["frac"] < 1.0
+    for wl in ("c4", "c5"):  # north_star: 1080p AND 4K at 1/2/4/8 GPUs
+        o = res["config"]["other_workloads"][wl]
+        assert "error" not in o and o["frames_per_s"] > 0 and o["hbm_frac"] > 0.2, o
+    for rt in ("NEAREST", "BICUBIC", "AREA"):
+        o = res["config"]["other_resize_types"][rt]
+        assert "error" not in o and o["frames_per_s"] > 0, o
+    t = res["timing"]
+    assert t["total_timed_steps"] == t["repeats"] * res["steps"] and t["mean_ms_per_step"] > 0
+    return res
+
+
+def test_torchrun_world1_nccl():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    res = _check(p)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_nccl_world1.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def test_force_dist_world1_nccl():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=_env(TSVPP_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=600)
+    _check(p)

@@ -46,6 +46,46 @@ def test_first_call_graph_capture_of_two_pass_formats(oracle, fourcc, norm):
     v.Close()
 
 
+@pytest.mark.parametrize("prepared", [True, False])
+@pytest.mark.parametrize("src,dst", [((1080, 608), (480, 360)), ((1920, 1080), (224, 224))])
+def test_first_call_graph_capture_of_float_weight_area(oracle, src, dst, prepared):
+    """a non-dyadic AREA down-scale uses a host-built divisor table (one entry per column pattern x row
+    pattern).  prepared: tsvpp_prepare_batch builds it, so the FIRST conversion may already be a captured one.  Not prepared (the
+    two weight tables exist -- built by two other requests that share one scale each -- but this request's divisor table does
+    not): nothing is allocated inside the capture and the conversion still succeeds, on the kernel that sums the weights itself."""
+    import tensor_stream as ts
+    v = ts.VideoProcessor(device=0)
+    n = 2
+    frames = [synth_nv12(src[0], src[1], seed=950 + i) for i in range(n)]
+    ys = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    uvs = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=3, pixel_format=RGB24, normalization=True, planes_pos=0)
+    s = torch.cuda.Stream()
+    if prepared:
+        v.prepare(fp, src[0], src[1], n_frames=n, stream=s.cuda_stream)
+    else:
+        # the weight rows of both scales exist (transposed request: x and y scales swapped -> another divisor-table key),
+        # the divisor table of THIS request does not
+        fpt = ts.FrameParameters(width=dst[1] * src[0] // src[1] // 2 * 2, height=dst[1], resize_type=3, pixel_format=RGB24, normalization=True, planes_pos=0)
+        v.prepare(fpt, src[0], src[1], n_frames=n, stream=s.cuda_stream)
+        v.prepare(ts.FrameParameters(width=dst[0], height=dst[0] * src[1] // src[0] // 2 * 2, resize_type=3, pixel_format=RGB24, normalization=True, planes_pos=0),
+                  src[0], src[1], n_frames=n, stream=s.cuda_stream)
+    out = v._alloc(fp.parameters, src[0], src[1], n)
+    batch = v.make_batch(ys, uvs, fp, out=out)
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):  # no warm-up call
+        v.run_batch(batch, torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    for i in range(n):
+        ref = oracle.convert(frames[i][0], frames[i][1], dst=dst, resize_type=3, fourcc=RGB24, planes=0, normalization=True, nthreads=4)[0]
+        assert np.array_equal(o[i].ravel().view(np.uint8), ref.view(np.uint8))
+    v.Close()
+
+
 def test_threads_sharing_the_null_stream_do_not_corrupt_the_scratch(oracle):
     """Two-pass formats keep their NV12 intermediate in a per-stream scratch: callers that share a stream (here the
     null stream) must neither interleave their passes on it nor free it under each other while it grows."""
