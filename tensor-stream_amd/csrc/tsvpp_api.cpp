@@ -217,6 +217,9 @@ struct tsvpp_ctx {
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
     int r32 = 1;                    // TSVPP_R32: streaming kernel for BILINEAR at exactly 3 : 2 with uint8 outputs
+    int bicubic_cols = 2;           // TSVPP_BICUBIC_COLS: wave-per-tile BICUBIC kernel (1: non-dyadic weights only, 2: every BICUBIC request, 0: off)
+    int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
+    int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
     GeoCache *geo = nullptr;        // ... their device copies, one set per (request geometry, tile shape)
     std::mutex area_mu;
@@ -321,6 +324,9 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_DMA")) ctx->bicubic_dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS_LDS")) ctx->area_cols_lds = std::atoi(e);
@@ -363,6 +369,9 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.area_direct_fmin = ctx->area_direct_fmin;
     d.bicubic_sep = ctx->bicubic_sep;
     d.bicubic_int_pref = ctx->bicubic_int;
+    d.bicubic_cols_pref = ctx->bicubic_cols;
+    d.bc_rows = ctx->bicubic_rows;
+    d.bc_dma_pref = ctx->bicubic_dma;
     d.area_box_pref = ctx->area_box;
     d.w_dyadic = pl.w_dyadic;
     d.bil_int_pref = ctx->bilinear_int;
@@ -707,7 +716,7 @@ int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int
         sts = scratch_grow(ctx, slot, scratch_frame_bytes(pl) * (size_t)n_frames);
         if (sts != TSVPP_OK) return sts;
     }
-    if ((pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) && ctx->geo_pref) {
+    if (((pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) && ctx->geo_pref) || (pl.mode == M_BICUBIC && ctx->bicubic_cols)) {
         // geometry tables of the 2x2-tap kernel: a dry run of the launch chooses the tile shape and builds them.  They do not
         // depend on the pitches (only their use does: multiples of 16) nor on the batch size beyond the tile shape -- a
         // conversion that ends up with another shape builds its own set on first use.

@@ -3,58 +3,82 @@
 // The reference's value is V(H(row y-1), H(row y), H(row y+1), H(row y+2)) with H the horizontal 4-tap Keys sum (a = -0.75)
 // of ONE source row, rounded and clamped to a byte, and V the same sum down the column (src/Resize.cu:27-91, 314-357).  H
 // depends only on (source row, output column) and neighbouring output rows share most of their source rows, so the
-// workgroup kernels of rounds 1 / 2 (vpp_bicubic_sep_kernel, vpp_bicubic_int_kernel) evaluated H once per (staged row, tile
-// column) into an LDS plane -- behind a whole-workgroup pipeline: stage the footprint, barrier, tables, H phase, barrier, V
-// phase.  Measured (profiles/r02_bicubic_fallback_bound.txt, r02_bicubic_pmc.txt): VALU ~30 % busy, four workgroups per CU,
-// 35 % of the LDS cycles bank conflicts -- bound by that structure, not by arithmetic or HBM.
+// workgroup kernels of rounds 1 / 2 evaluated H once per (staged row, tile column) into an LDS plane -- behind a
+// whole-workgroup pipeline: stage the footprint, barrier, tables, H phase, barrier, V phase.  Measured
+// (profiles/r02_bicubic_fallback_bound.txt, r02_bicubic_pmc.txt): VALU ~30 % busy, four workgroups per CU, 35 % of the LDS
+// cycles bank conflicts -- bound by that structure, not by arithmetic or HBM.
 //
-// Here nothing is staged and no workgroup barrier exists.  A wave owns 64 output columns x R output rows:
-//   phase 1  lane j walks DOWN the source rows of the tile; per row it loads the eight bytes around its own four taps
-//            straight from global memory (adjacent lanes read adjacent, overlapping windows: every 128-byte line is fetched
-//            once per wave instruction), selects the taps with one v_perm_b32 (the reference's edge rule -- the +1 AND +2
-//            taps collapse, src/Resize.cu:32-43 -- lives in the selector), and writes H of four consecutive rows as ONE dword
-//            of its private column in a wave-private, column-major LDS plane (column stride = an odd number of dwords: no
-//            bank conflicts);
+// Here no workgroup barrier exists.  A wave owns 64 output columns x R output rows:
+//   phase 1  lane j walks DOWN the source rows of the tile, four rows per step.  The row segments the wave needs are fetched
+//            by LDS-DMA (global_load_lds_dword: lane l fetches dword l of the segment, one instruction per row, no VGPRs) into
+//            a wave-private ring of 16 rows, so that 12-16 rows are in flight per wave while it computes; at horizontal
+//            ratios >= 3.8 (a lane's taps are then disjoint from its neighbours') every lane loads its own eight bytes
+//            straight into registers, one group ahead.  A lane picks its four taps out of two aligned dwords with one
+//            v_perm_b32 -- the reference's edge rule (the +1 AND +2 taps collapse, src/Resize.cu:32-43) lives in the selector --
+//            and writes H of four consecutive rows as ONE dword of its private column in a wave-private, column-major LDS
+//            plane (column stride = an odd number of dwords: no bank conflicts);
 //   phase 2  the four vertical taps of an output row are four consecutive bytes of that column: two dword reads,
 //            v_alignbyte_b32, v_perm_b32 (vertical edge rule), the same 4-tap sum; per-row parameters are wave-uniform: each
-//            lane evaluates ONE row's coordinates, the loop fetches them with v_readlane_b32 (no table in LDS, no barrier);
+//            lane evaluates ONE row's coordinates and coefficients, the loop fetches them with v_readlane_b32 (no table in
+//            LDS, no barrier);
 //   chroma   is the same two phases on the interleaved UV plane with lane = (pair column, U | V) and a tap stride of 2;
 //   colour   the resized tile goes through a small wave-private byte tile into the usual 2 x 4 thread tiles (colour
 //            conversion, every output flavour, vector stores: color_store_tile).
-// LDS operations of one wave execute in order, so nothing but wave-level fences separates the phases; 8 workgroups of 4
-// independent waves fit a CU.  Rows the vertical taps skip (ratios >= 4) are not evaluated: there the H plane holds the
-// four taps of each output row instead of a contiguous run of source rows ("sparse" mode).
+// LDS operations of one wave execute in order, so nothing but wave-level fences separates the phases.  Rows the vertical
+// taps skip (ratios >= 4) are not evaluated: there the H plane holds the four taps of each output row instead of a contiguous
+// run of source rows ("sparse" mode).
 //
-// Arithmetic: exactly the round-1 scheme (vpp_device.h: cubic4_pair): the reference's fp64 sum is evaluated in fp32 pairs and
-// redone in fp64, as the reference does it, whenever the fp32 sum is within 5e-4 of a rounding tie.  INT = true (host: every
-// weight of the request is a multiple of 1/16): the integer evaluation of vpp_bicubic_int.hip -- coefficients x 2^14 in
-// int16, two v_dot2_i32_i16 per sum, v_ashr_pk_u8_i32 -- in the same wave structure.
+// Arithmetic.  The reference evaluates sum_k c_k(w) p_k in fp64 and rounds half away from zero.  Here the coefficients are
+// evaluated in fp64 ONCE per column / row and quantised to C_k = rint(c_k 2^22); the sum of C_k p_k is then exact in 32-bit
+// integers (|sum| <= 255 * 1.375 * 2^22 < 2^31) and differs from 2^22 times the reference's sum by at most 4 * 255 * 2^-23
+// * 2^22 = 510 units.  Whenever the integer sum is further than that from a rounding tie, (S + 2^21) >> 22 IS the
+// reference's value; the few lanes within reach of a tie redo the sum in fp64 exactly as the reference does (~0.03 % of
+// the sums).  The integer sum is three v_dot4_u32_u8 on the four packed taps: |C_k| = l2 2^16 + l1 2^8 + l0 in base-256
+// digits, and since Keys' coefficients have fixed signs (c0, c3 <= 0 <= c1, c2) the two negative ones are applied to the
+// complemented taps 255 - t (one XOR on the packed taps; the constant 255 (|C_0| + |C_3|) is part of the bias) -- 6 VALU
+// operations per sum instead of 15 in packed fp32.  EXACT = true (host: every weight of the request is a
+// multiple of 1/16, so every C_k is exact): no tie test at all, a tie rounds up as round() does for positive values and
+// negative values clamp to 0 either way.
 #include "vpp_device.h"
+
+#include <vector>
 
 #pragma clang fp contract(off)
 
 namespace tsvpp {
 
-typedef short s16x2c __attribute__((ext_vector_type(2)));
+// The tables are written by the host before the launch and never by a kernel: read through the CONSTANT address space, loads
+// at wave-uniform addresses (the rows' entries) become scalar loads (s_load_dwordx8: no VALU, no VGPRs).
+typedef const __attribute__((address_space(4))) BcEntry *BcTab;
+typedef int bc_i4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) int *BcRows;     // seven arrays of `np` ints: ws | sel | l0 | l1 | l2 | bias | w
+typedef const __attribute__((address_space(4))) bc_i4 *BcRows4;
+__device__ __forceinline__ BcTab bc_const(const BcEntry *p) { return (BcTab)(uintptr_t)p; }
+__device__ __forceinline__ BcEntry bc_ld(BcTab p) {
+    BcEntry e;
+    e.ws = p->ws; e.sel = p->sel; e.l0 = p->l0; e.l1 = p->l1; e.l2 = p->l2; e.bias = p->bias; e.w = p->w; e.maxoff = p->maxoff;
+    return e;
+}
+
 typedef uint32_t u32x2a4c __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint32_t u32x3a4c __attribute__((ext_vector_type(3), aligned(4)));
 
-// One axis position: first sample of the 4-sample window, the tap selector (byte k = offset of tap k from the window start,
-// 0..3: the reference's edge rule), weight and coefficients.
-struct BcAxis {
-    int ws;        // window start (sample units of that grid)
-    uint32_t sel;  // tap offsets from ws, one per byte
-    int maxoff;    // largest tap offset
-    float w;
-    float c[4];
-    int c01, c23;  // INT: folded integer coefficients per WINDOW offset (vpp_bicubic_int.hip)
-};
+constexpr int BC_SHIFT = 22;             // coefficient scale 2^22
+constexpr int BC_TIE = 560;              // tie zone in units of 2^-22 (error bound 510)
+constexpr int BC_RING_ROWS = 16;         // rows of the LDS-DMA ring (four groups of four)
 
+// byte k of a dword as a float: the compiler selects v_cvt_f32_ubyte<k>
+__device__ __forceinline__ float ub0(uint32_t v) { return (float)(v & 255u); }
+__device__ __forceinline__ float ub1(uint32_t v) { return (float)((v >> 8) & 255u); }
+__device__ __forceinline__ float ub2(uint32_t v) { return (float)((v >> 16) & 255u); }
+__device__ __forceinline__ float ub3(uint32_t v) { return (float)(v >> 24); }
+
+// One output index along one axis -> its table entry (vpp_kernels.h: BcEntry).  Evaluated on the HOST, once per request
+// (bicubic_cols_tables): round 3's first version evaluated it per wave and spent a third of its VALU instructions here.
 // `clamp_limit`: the size the coordinate clamps use (the LUMA size on both grids, src/Resize.cu:325-347); `tap_limit`: the
 // size the edge rule uses, in samples of this grid.
-template <bool INT>
-__device__ __forceinline__ BcAxis bc_axis(int idx, float ratio, int clamp_limit, int tap_limit) {
-    BcAxis a;
+static BcEntry bc_axis(int idx, float ratio, int clamp_limit, int tap_limit) {
+    BcEntry a;
     int p;
     double w;
     bicubic_axis(idx, ratio, clamp_limit, p, w);
@@ -64,189 +88,261 @@ __device__ __forceinline__ BcAxis bc_axis(int idx, float ratio, int clamp_limit,
     a.sel = (uint32_t)lo << 8 | (uint32_t)(lo + hi) << 16 | (uint32_t)(lo + 2 * hi) << 24;
     a.maxoff = lo + 2 * hi;
     a.w = (float)w; // exact: the fraction of a float coordinate
-    cubic_coeffs_f(a.w, a.c);
-    a.c01 = a.c23 = 0;
-    if constexpr (INT) { // exact for w = k / 16; a collapsed tap's coefficient moves onto the sample it collapsed on
-        const int C[4] = { (int)(a.c[0] * 16384.0f), (int)(a.c[1] * 16384.0f), (int)(a.c[2] * 16384.0f), (int)(a.c[3] * 16384.0f) };
-        int wg[4] = { 0, 0, 0, 0 };
-        const int off[4] = { 0, lo, lo + hi, lo + 2 * hi };
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int o = 0; o < 4; o++) wg[o] += (off[k] == o) ? C[k] : 0;
-        a.c01 = (wg[0] & 0xffff) | (wg[1] << 16);
-        a.c23 = (wg[2] & 0xffff) | (wg[3] << 16);
-        a.maxoff = min(3, tap_limit - 1 - a.ws); // the window is always four consecutive samples; those past the plane carry weight 0
+    double c[4];
+    cubic_coeffs(w, c);
+    // Keys' coefficients have fixed signs (a = -0.75, w in [0, 1)): c0, c3 <= 0 <= c1, c2.  With m_k = |C_k| as three planes of
+    // UNSIGNED base-256 digits and the taps 0 and 3 complemented (255 - t: one XOR 0xFF0000FF on the packed taps),
+    //     sum_k C_k t_k = sum_k m_k x_k - 255 (m_0 + m_3)      -- three v_dot4_u32_u8, the constant is part of the bias
+    uint32_t d0 = 0, d1 = 0, d2 = 0;
+    int neg = 0;
+    for (int k = 0; k < 4; k++) {
+        const int C = (int)__builtin_rint(c[k] * 4194304.0);
+        const int m = (k == 0 || k == 3) ? -C : C; // >= 0, <= 2^22
+        d0 |= (uint32_t)(m & 255) << (8 * k);
+        d1 |= (uint32_t)((m >> 8) & 255) << (8 * k);
+        d2 |= (uint32_t)((m >> 16) & 255) << (8 * k);
+        if (k == 0 || k == 3) neg += m;
     }
+    a.l0 = (int)d0;
+    a.l1 = (int)d1;
+    a.l2 = (int)d2;
+    a.bias = (1 << (BC_SHIFT - 1)) - 255 * neg;
     return a;
 }
 
-// Two 4-tap sums on packed taps (tap k of sum 0 / 1 in byte k of t0 / t1) -> two integer-valued floats in [0, 255].
-__device__ __forceinline__ f2 bc_sum_pair(uint32_t t0, uint32_t t1, float w0, float w1, const float c0[4], const float c1[4]) {
-    f2 p[4];
-    p[0] = (f2){ __builtin_amdgcn_cvt_f32_ubyte0(t0), __builtin_amdgcn_cvt_f32_ubyte0(t1) };
-    p[1] = (f2){ __builtin_amdgcn_cvt_f32_ubyte1(t0), __builtin_amdgcn_cvt_f32_ubyte1(t1) };
-    p[2] = (f2){ __builtin_amdgcn_cvt_f32_ubyte2(t0), __builtin_amdgcn_cvt_f32_ubyte2(t1) };
-    p[3] = (f2){ __builtin_amdgcn_cvt_f32_ubyte3(t0), __builtin_amdgcn_cvt_f32_ubyte3(t1) };
-    f2 s = ((f2){ c0[0], c1[0] } * p[0] + (f2){ c0[1], c1[1] } * p[1]) + (f2){ c0[2], c1[2] } * p[2];
-    s = s + (f2){ c0[3], c1[3] } * p[3];
-    const f2 magic = { 12582912.0f, 12582912.0f };
-    f2 r = (s + magic) - magic; // nearest even: differs from the reference's half-away rule only AT a tie, and those are redone
-    const f2 dd = s - r;
-    r.x = __builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f);
-    r.y = __builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);
-    const bool tie0 = fabsf(dd.x) > 0.5f - CUBIC_DELTA, tie1 = fabsf(dd.y) > 0.5f - CUBIC_DELTA;
-    if (tie0 || tie1) { // rarely taken: the reference's own fp64 evaluation decides
-        if (tie0) {
-            double c[4];
-            cubic_coeffs((double)w0, c);
-            r.x = (float)cubic4(c, (int)(t0 & 255u), (int)((t0 >> 8) & 255u), (int)((t0 >> 16) & 255u), (int)(t0 >> 24));
-        }
-        if (tie1) {
-            double c[4];
-            cubic_coeffs((double)w1, c);
-            r.y = (float)cubic4(c, (int)(t1 & 255u), (int)((t1 >> 8) & 255u), (int)((t1 >> 16) & 255u), (int)(t1 >> 24));
+// 2^22 x the 4-tap sum over the packed taps (tap k in byte k) + 2^21: the value is clamp(that >> 22, 0, 255)
+__device__ __forceinline__ int bc_isum(uint32_t taps, int l0, int l1, int l2, int bias) {
+    const uint32_t x = taps ^ 0xff0000ffu; // taps 0 and 3 complemented: their coefficients are <= 0
+    const uint32_t s0 = __builtin_amdgcn_udot4(x, (uint32_t)l0, (uint32_t)bias, false);
+    const uint32_t s1 = __builtin_amdgcn_udot4(x, (uint32_t)l1, 0u, false);
+    const uint32_t s2 = __builtin_amdgcn_udot4(x, (uint32_t)l2, 0u, false);
+    return (int)((((s2 << 8) + s1) << 8) + s0);
+}
+// distance-to-tie key: small (< 2 BC_TIE << 10) iff the sum is within BC_TIE units of a rounding tie
+__device__ __forceinline__ uint32_t bc_tie_key(int s) { return (uint32_t)(s + BC_TIE) << (32 - BC_SHIFT); }
+constexpr uint32_t BC_TIE_KEY = (2u * BC_TIE) << (32 - BC_SHIFT);
+// the reference's own evaluation (fp64, round half away, clamp) of one sum
+__device__ __forceinline__ uint32_t bc_exact(uint32_t taps, float w) {
+    double c[4];
+    cubic_coeffs((double)w, c);
+    return (uint32_t)cubic4(c, (int)(taps & 255u), (int)((taps >> 8) & 255u), (int)((taps >> 16) & 255u), (int)(taps >> 24));
+}
+// Four sums -> four bytes clamp(s >> 22, 0, 255), s0 in byte 0.  gfx950's V_ASHR_PK_U8_I32 shifts, saturates and packs two
+// values into the LOW half of its destination and keeps the upper half (measured; see vpp_bicubic_int.hip): pair (s2, s3) is
+// packed first and shifted up, pair (s0, s1) then lands below it.
+__device__ __forceinline__ uint32_t bc_pack4(int s0, int s1, int s2, int s3) {
+    uint32_t hi;
+    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(hi) : "v"(s2), "v"(s3));
+    uint32_t r = hi << 16;
+    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 22" : "+v"(r) : "v"(s0), "v"(s1));
+    return r;
+}
+// four sums -> four result bytes; the (rare) sums within reach of a tie are redone as the reference does them
+template <bool EXACT>
+__device__ __forceinline__ uint32_t bc_finish4(const int s[4], const uint32_t tp[4], float w0, float w1, float w2, float w3) {
+    uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
+    if constexpr (!EXACT) {
+        const uint32_t k0 = bc_tie_key(s[0]), k1 = bc_tie_key(s[1]), k2 = bc_tie_key(s[2]), k3 = bc_tie_key(s[3]);
+        if (min(min(k0, k1), min(k2, k3)) < BC_TIE_KEY) { // rarely taken
+            if (k0 < BC_TIE_KEY) r = (r & 0xffffff00u) | bc_exact(tp[0], w0);
+            if (k1 < BC_TIE_KEY) r = (r & 0xffff00ffu) | bc_exact(tp[1], w1) << 8;
+            if (k2 < BC_TIE_KEY) r = (r & 0xff00ffffu) | bc_exact(tp[2], w2) << 16;
+            if (k3 < BC_TIE_KEY) r = (r & 0x00ffffffu) | bc_exact(tp[3], w3) << 24;
         }
     }
     return r;
 }
-// INT: S + 8192 of the 4-tap sum over the window bytes of q; the value is clamp(that >> 14, 0, 255)
-__device__ __forceinline__ int bc_isum(uint32_t q, int c01, int c23) {
-    const uint32_t p01 = __builtin_amdgcn_perm(0u, q, 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, q, 0x0c030c02u);
-    int s = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2c, p01), __builtin_bit_cast(s16x2c, c01), 8192, false);
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2c, p23), __builtin_bit_cast(s16x2c, c23), s, false);
-}
-// four biased sums -> four bytes (vpp_bicubic_int.hip: round_clamp_pack4; the instruction keeps the upper half of its destination)
-__device__ __forceinline__ uint32_t bc_pack4(int s0, int s1, int s2, int s3) {
-    uint32_t hi;
-    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 14" : "=v"(hi) : "v"(s2), "v"(s3));
-    uint32_t r = hi << 16;
-    asm("s_nop 2\n\tv_ashr_pk_u8_i32 %0, %1, %2, 14" : "+v"(r) : "v"(s0), "v"(s1));
-    return r;
-}
-__device__ __forceinline__ uint32_t bc_pack4f(f2 a, f2 b) { // integer-valued floats in [0, 255]
-    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0u, 0u);
-    r = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1u, r);
-    r = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2u, r);
-    return __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3u, r);
-}
 __device__ __forceinline__ uint32_t rep4(uint32_t b) { return __builtin_amdgcn_perm(0u, b, 0u); } // byte 0 into all four bytes
 
-// The window bytes of one lane in one source row.  `plane` is the frame's plane pointer rounded down to a dword (uniform),
-// `a` the byte offset of the lane's window start from it (row * pitch + window start + rounding), `need` the last window byte
-// the taps read.  NDW = 2 (luma: 8 bytes cover any 4-byte window) or 3 (chroma: taps 2 apart, 7-byte window).  `last`: the
-// row is the plane's last one -- a dword past the last needed byte is then re-pointed at the first, nothing is read beyond the
-// dword of the last needed byte; every other row may over-read into the next row of the same plane.
-template <int NDW>
-__device__ __forceinline__ void bc_load(const uint8_t *plane, uint32_t a, int need, bool last, uint32_t (&dw)[NDW]) {
-    const uint32_t *p = (const uint32_t *)(plane + (a & ~3u));
-    if (!last) {
-        if constexpr (NDW == 2) {
-            const u32x2a4c v = *(const u32x2a4c *)p;
-            dw[0] = v.x; dw[1] = v.y;
-        } else {
-            const u32x3a4c v = *(const u32x3a4c *)p;
-            dw[0] = v.x; dw[1] = v.y; dw[2] = v.z;
-        }
+// packed taps of one row from the dwords around the window: `sh` = byte offset of the window start in dw[0]; STEP 1: `selx` =
+// tap selector + sh in every byte; STEP 2 (chroma, taps 2 bytes apart): `selx` = twice the tap selector
+template <int STEP, int NDW>
+__device__ __forceinline__ uint32_t bc_taps(const uint32_t (&dw)[NDW], uint32_t sh, uint32_t selx) {
+    if constexpr (STEP == 1) {
+        return __builtin_amdgcn_perm(dw[1], dw[0], selx);
     } else {
-        const int hi = (int)(a & 3u) + need; // last needed byte, from the aligned dword
-#pragma unroll
-        for (int k = 0; k < NDW; k++) dw[k] = p[(4 * k <= hi) ? k : 0];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(dw[1], dw[0], sh), a1 = __builtin_amdgcn_alignbyte(dw[2], dw[1], sh);
+        return __builtin_amdgcn_perm(a1, a0, selx);
     }
 }
 
 // One plane (luma: STEP 1, lane = column; chroma: STEP 2, lane = (pair column, component)) through phases 1 and 2.
-// hp: this wave's H plane for the plane (byte address of the LANE's column); res: the wave's result tile (row-major, 64 bytes
-// per row), nout output rows.  ax: the lane's column; rows come from the lanes `rl0 ...` of the row registers (v_readlane).
-template <bool INT, int STEP>
-__device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int pitch, int rows_in_plane, const BcAxis &ax, int comp, bool sparse,
-                                         uint8_t *hcol, uint8_t *res, int lane, int nout, int rl0, const BcAxis &rw) {
+// ax: the lane's column; rows: the tile's first row entry (wave-uniform pointer: scalar loads); hcol: this lane's column of
+// the wave's H plane; ring: the wave's LDS-DMA ring (DMA mode); res: the wave's result tile (row-major, 64 bytes per row).
+template <bool EXACT, int STEP>
+__device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int pitch, int rows_in_plane, int row_bytes, const BcEntry &ax, int comp,
+                                         bool sparse, bool dma, uint8_t *ring, uint8_t *hcol, uint8_t *res, int lane, int nout, BcRows rows, int np) {
     constexpr int NDW = STEP == 1 ? 2 : 3;
-    // ---- phase 1: H of every needed source row of this lane's column, four rows per dword
-    const uint32_t xoff = pm + (uint32_t)(STEP * ax.ws + comp);
-    const int xneed = STEP * ax.maxoff;
-    const int ws0 = __builtin_amdgcn_readlane(rw.ws, rl0), wsl = __builtin_amdgcn_readlane(rw.ws, rl0 + nout - 1);
-    const int ylo = ws0, yhi = min(wsl + 3, rows_in_plane - 1); // dense: every row from the first window's start to the last window's end
+    const int ylo = rows[0], yhi = min(rows[nout - 1] + 3, rows_in_plane - 1); // dense: every row from the first window's start to the last window's end
     const int ng = sparse ? nout : ((yhi - ylo + 1 + 3) >> 2);
-    for (int g = 0; g < ng; g++) {
-        int rr[4];
-        if (sparse) { // the four taps of output row g, in tap order
-            const int ws = __builtin_amdgcn_readlane(rw.ws, rl0 + g);
-            const uint32_t sel = (uint32_t)__builtin_amdgcn_readlane((int)rw.sel, rl0 + g);
+    // source rows of group g: the four taps of output row g in tap order (sparse), or four consecutive rows (dense)
+    auto group_rows = [&](int g, int (&rr)[4]) {
+        if (sparse) {
+            const int ws = rows[g];
+            const uint32_t sel = (uint32_t)rows[np + g];
 #pragma unroll
             for (int k = 0; k < 4; k++) rr[k] = ws + (int)((sel >> (8 * k)) & 255u);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) rr[k] = min(ylo + 4 * g + k, yhi);
         }
-        uint32_t dw[4][NDW], sh[4];
+    };
+    const int xb = STEP * ax.ws + comp; // the lane's window start, byte column of the plane
+    const uint32_t tapsel = STEP == 1 ? ax.sel : ax.sel + ax.sel;
+    const bool aligned = (pitch & 3) == 0; // every row then has the same misalignment: lane addresses and selectors are loop-invariant
+    // ---- phase 1: H of every needed source row of this lane's column, four rows per dword
+    if (dma) {
+        // the wave's row segment: bytes [xb0, xbl + 3 STEP] of a row, fetched as nd aligned dwords by lanes 0 .. nd - 1
+        const int xb0 = __builtin_amdgcn_readlane(xb, 0), xbl = __builtin_amdgcn_readlane(xb, 63);
+        const int nd = (xbl + 3 * STEP - xb0 + 1 + 3 + 3) >> 2;
+        const int rowb = 4 * nd;
+        const uint32_t lane4 = 4u * (uint32_t)lane;
+        auto issue = [&](int g) {
+            int rr[4];
+            group_rows(g, rr);
+            if (lane < nd) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t a = (uint32_t)rr[k] * (uint32_t)pitch + xoff;
-            sh[k] = a & 3u;
-            bc_load<NDW>(plane, a, xneed, rr[k] >= rows_in_plane - 1, dw[k]);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t r0 = (uint32_t)rr[k] * (uint32_t)pitch + pm;
+                    const uint32_t seg = (r0 + (uint32_t)xb0) & ~3u, seg_last = (r0 + (uint32_t)row_bytes - 1u) & ~3u; // never past the row's last dword
+                    const uint8_t *src = plane + min(seg + lane4, seg_last);
+                    uint8_t *dst = ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb; // wave-uniform
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+                }
+            }
+        };
+        const int npre = min(BC_RING_ROWS / 4, ng);
+        for (int g = 0; g < npre; g++) issue(g);
+        // aligned: the lane's dword offset inside a ring row and its shifted selector, once
+        const uint32_t a_c = (uint32_t)(xb - xb0) + ((pm + (uint32_t)xb0) & 3u);
+        const uint32_t al_c = a_c & ~3u, sh_c = a_c & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
+        for (int g = 0; g < ng; g++) {
+            // group g has landed when at most the later groups' loads are outstanding (4 per group)
+            const int later = min(BC_RING_ROWS / 4 - 1, ng - 1 - g);
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t tp[4];
+            if (aligned) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t *p = (const uint32_t *)(ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb + al_c);
+                    uint32_t dw[NDW];
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) dw[q] = p[q];
+                    tp[k] = bc_taps<STEP, NDW>(dw, sh_c, selx_c);
+                }
+            } else {
+                int rr[4];
+                group_rows(g, rr);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t shr = ((uint32_t)rr[k] * (uint32_t)pitch + pm + (uint32_t)xb0) & 3u; // the segment's misalignment (uniform)
+                    const uint32_t a = (uint32_t)(xb - xb0) + shr;
+                    const uint32_t *p = (const uint32_t *)(ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb + (a & ~3u));
+                    uint32_t dw[NDW];
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) dw[q] = p[q];
+                    tp[k] = bc_taps<STEP, NDW>(dw, a & 3u, STEP == 1 ? tapsel + rep4(a & 3u) : tapsel);
+                }
+            }
+            if (g + BC_RING_ROWS / 4 < ng) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the ring slots of group g have been read
+                issue(g + BC_RING_ROWS / 4);
+            }
+            int s[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
+            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
         }
-        uint32_t tp[4]; // packed taps (float) / window bytes (INT) of the four rows
+    } else {
+        // direct mode: every lane loads the NDW dwords around its own window, one group ahead
+        const uint32_t xoff = pm + (uint32_t)xb;
+        const int xneed = STEP * ax.maxoff;
+        const uint32_t sh_c = xoff & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
+        uint32_t cur[4][NDW], csh[4];
+        auto fetch = [&](int g, uint32_t (&dw)[4][NDW], uint32_t (&sh)[4]) {
+            int rr[4];
+            group_rows(g, rr);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if constexpr (STEP == 1) {
-                if constexpr (INT) tp[k] = __builtin_amdgcn_alignbyte(dw[k][1], dw[k][0], sh[k]);
-                else tp[k] = __builtin_amdgcn_perm(dw[k][1], dw[k][0], ax.sel + rep4(sh[k]));
-            } else { // bytes sh .. sh + 7 of the three dwords, then every second one
-                const uint32_t a0 = __builtin_amdgcn_alignbyte(dw[k][1], dw[k][0], sh[k]), a1 = __builtin_amdgcn_alignbyte(dw[k][2], dw[k][1], sh[k]);
-                if constexpr (INT) tp[k] = __builtin_amdgcn_perm(a1, a0, 0x06040200u);
-                else tp[k] = __builtin_amdgcn_perm(a1, a0, ax.sel + ax.sel); // tap offsets in bytes: 2 x
+            for (int k = 0; k < 4; k++) {
+                const uint32_t a = (uint32_t)rr[k] * (uint32_t)pitch + xoff; // aligned: a & 3 == sh_c whatever the row
+                sh[k] = a & 3u;
+                // aligned: (row * pitch + xoff) & ~3 == row * pitch + (xoff & ~3): a wave-uniform row pointer + a loop-invariant lane offset
+                const uint32_t *p = aligned ? (const uint32_t *)(plane + (size_t)((uint32_t)rr[k] * (uint32_t)pitch) + (xoff & ~3u))
+                                            : (const uint32_t *)(plane + (a & ~3u));
+                if (rr[k] < rows_in_plane - 1) { // not the plane's last row: the bytes after the window belong to the plane
+                    if constexpr (NDW == 2) {
+                        const u32x2a4c v = *(const u32x2a4c *)p;
+                        dw[k][0] = v.x; dw[k][1] = v.y;
+                    } else {
+                        const u32x3a4c v = *(const u32x3a4c *)p;
+                        dw[k][0] = v.x; dw[k][1] = v.y; dw[k][2] = v.z;
+                    }
+                } else { // a dword past the last needed byte is re-pointed at the first: nothing is read beyond the last needed byte's dword
+                    const int hi = (int)sh[k] + xneed;
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) dw[k][q] = p[(4 * q <= hi) ? q : 0];
+                }
+            }
+        };
+        fetch(0, cur, csh);
+        for (int g = 0; g < ng; g++) {
+            uint32_t nxt[4][NDW] = {}, nsh[4] = {};
+            if (g + 1 < ng) fetch(g + 1, nxt, nsh); // one group ahead
+            uint32_t tp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tp[k] = aligned ? bc_taps<STEP, NDW>(cur[k], sh_c, selx_c) : bc_taps<STEP, NDW>(cur[k], csh[k], STEP == 1 ? tapsel + rep4(csh[k]) : tapsel);
+            int s[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
+            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                csh[k] = nsh[k];
+#pragma unroll
+                for (int q = 0; q < NDW; q++) cur[k][q] = nxt[k][q];
             }
         }
-        uint32_t h4;
-        if constexpr (INT) {
-            h4 = bc_pack4(bc_isum(tp[0], ax.c01, ax.c23), bc_isum(tp[1], ax.c01, ax.c23), bc_isum(tp[2], ax.c01, ax.c23), bc_isum(tp[3], ax.c01, ax.c23));
-        } else {
-            h4 = bc_pack4f(bc_sum_pair(tp[0], tp[1], ax.w, ax.w, ax.c, ax.c), bc_sum_pair(tp[2], tp[3], ax.w, ax.w, ax.c, ax.c));
-        }
-        *(uint32_t *)(hcol + 4 * g) = h4;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- phase 2: vertical sums, two output rows per step
-    for (int i = 0; i < nout; i += 2) {
-        uint32_t tp[2];
-        float wv[2], cv[2][4];
-        int ic01[2], ic23[2];
+    // ---- phase 2: vertical sums, four output rows per step.  The rows' parameters are wave-uniform: ONE scalar load per array
+    // fetches them for the step's four rows (the arrays are padded, so a partial last step reads valid entries it does not store).
+    for (int i = 0; i < nout; i += 4) {
+        const bc_i4 ws4 = *(BcRows4)(rows + i), sel4 = *(BcRows4)(rows + np + i), a4 = *(BcRows4)(rows + 2 * np + i), b4 = *(BcRows4)(rows + 3 * np + i),
+                    c4 = *(BcRows4)(rows + 4 * np + i), bias4 = *(BcRows4)(rows + 5 * np + i);
+        uint32_t tp[4];
+        int s[4];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int rl = rl0 + min(i + e, nout - 1);
-            const int off = sparse ? 4 * min(i + e, nout - 1) : __builtin_amdgcn_readlane(rw.ws, rl) - ylo;
+        for (int e = 0; e < 4; e++) {
+            const int off = sparse ? 4 * (i + e) : max(ws4[e] - ylo, 0); // (entries past the tile's last row: clamped into the column)
             const uint32_t *p = (const uint32_t *)(hcol + (off & ~3));
             const uint32_t win = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off & 3u);
-            if constexpr (INT) {
-                tp[e] = win;
-                ic01[e] = __builtin_amdgcn_readlane(rw.c01, rl);
-                ic23[e] = __builtin_amdgcn_readlane(rw.c23, rl);
-            } else {
-                const uint32_t sel = sparse ? 0x03020100u : (uint32_t)__builtin_amdgcn_readlane((int)rw.sel, rl);
-                tp[e] = __builtin_amdgcn_perm(0u, win, sel);
-                wv[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rw.w), rl));
-#pragma unroll
-                for (int k = 0; k < 4; k++) cv[e][k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rw.c[k]), rl));
+            tp[e] = __builtin_amdgcn_perm(0u, win, sparse ? 0x03020100u : (uint32_t)sel4[e]);
+            s[e] = bc_isum(tp[e], a4[e], b4[e], c4[e], bias4[e]);
+        }
+        uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
+        if constexpr (!EXACT) {
+            const uint32_t k0 = bc_tie_key(s[0]), k1 = bc_tie_key(s[1]), k2 = bc_tie_key(s[2]), k3 = bc_tie_key(s[3]);
+            if (min(min(k0, k1), min(k2, k3)) < BC_TIE_KEY) { // rarely taken
+                // (four scalar dword loads: ROCm 7.2's clang, given ONE dwordx4 load here, used element 0 for all four weights)
+                const BcRows wp = rows + 6 * np + i;
+                if (k0 < BC_TIE_KEY) r = (r & 0xffffff00u) | bc_exact(tp[0], __builtin_bit_cast(float, wp[0]));
+                if (k1 < BC_TIE_KEY) r = (r & 0xffff00ffu) | bc_exact(tp[1], __builtin_bit_cast(float, wp[1])) << 8;
+                if (k2 < BC_TIE_KEY) r = (r & 0xff00ffffu) | bc_exact(tp[2], __builtin_bit_cast(float, wp[2])) << 16;
+                if (k3 < BC_TIE_KEY) r = (r & 0x00ffffffu) | bc_exact(tp[3], __builtin_bit_cast(float, wp[3])) << 24;
             }
         }
-        uint32_t v0, v1;
-        if constexpr (INT) {
-            const uint32_t pk = bc_pack4(bc_isum(tp[0], ic01[0], ic23[0]), bc_isum(tp[1], ic01[1], ic23[1]), 0, 0);
-            v0 = pk & 255u;
-            v1 = (pk >> 8) & 255u;
-        } else {
-            const f2 v = bc_sum_pair(tp[0], tp[1], wv[0], wv[1], cv[0], cv[1]);
-            v0 = (uint32_t)v.x;
-            v1 = (uint32_t)v.y;
-        }
-        res[i * 64 + lane] = (uint8_t)v0;
-        if (i + 1 < nout) res[(i + 1) * 64 + lane] = (uint8_t)v1;
+        res[i * 64 + lane] = (uint8_t)r;
+        if (i + 1 < nout) res[(i + 1) * 64 + lane] = (uint8_t)(r >> 8);
+        if (i + 2 < nout) res[(i + 2) * 64 + lane] = (uint8_t)(r >> 16);
+        if (i + 3 < nout) res[(i + 3) * 64 + lane] = (uint8_t)(r >> 24);
     }
 }
 
-template <int OUT, bool INT>
+template <int OUT, bool EXACT>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
     const TileId id = decode_tile(d);
@@ -256,27 +352,24 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
     const int j_first = id.tx * 256 + wave * 64, i_first = id.ty * R;
     if (j_first >= d.dst_w) return; // (no workgroup barrier anywhere in this kernel)
     const int nrows = min(R, d.dst_h - i_first), ncrows = nrows >> 1;
-    const bool sparse = d.bc_sparse != 0;
+    const bool sparse = d.bc_sparse != 0, dma = d.bc_dma != 0;
 
-    // wave-private LDS: H planes (column-major, one column per lane), result tiles (row-major)
+    // wave-private LDS: DMA ring, H plane (column-major, one column per lane; luma then chroma), result tiles (row-major)
     uint8_t *wl = lds_raw + wave * d.bc_wave_bytes;
-    uint8_t *hy = wl + lane * d.hcs_y, *huv = wl + 64 * d.hcs_y + lane * d.hcs_uv;
-    uint8_t *yt = wl + 64 * (d.hcs_y + d.hcs_uv), *uvt = yt + 64 * R;
+    uint8_t *ring = wl, *hcol = wl + d.bc_ring_bytes + lane * d.hcs_y;
+    uint8_t *yt = wl + d.bc_ring_bytes + 64 * d.hcs_y, *uvt = yt + 64 * R;
 
-    // rows: lane r < 32 evaluates luma output row i_first + r, lane 32 + r chroma row i_first / 2 + r (the luma formulas on
-    // the chroma grid, clamps against the luma height: src/Resize.cu:325-347)
-    const bool crow = lane >= 32;
-    const int ridx = crow ? min((i_first >> 1) + (lane - 32), (d.dst_h >> 1) - 1) : min(i_first + lane, d.dst_h - 1);
-    const BcAxis rw = bc_axis<INT>(ridx, d.yr, d.src_h, crow ? (d.src_h >> 1) : d.src_h);
-
+    // the request's tables (host-built): luma columns | chroma pair columns | luma rows | chroma rows
+    const BcTab col_y = bc_const(d.bc_tab), col_c = col_y + d.dst_w;
+    const BcRows row_y = (BcRows)(col_c + (d.dst_w >> 1)), row_c = row_y + 7 * d.bc_npy;
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
     { // luma: lane = column (columns past the frame repeat the last one; never stored)
-        const BcAxis ax = bc_axis<INT>(min(j_first + lane, d.dst_w - 1), d.xr, d.src_w, d.src_w);
-        bc_plane<INT, 1>(t.y[id.frame] - ym, ym, d.pitch_y, d.src_h, ax, 0, sparse, hy, yt, lane, nrows, 0, rw);
+        const BcEntry ax = bc_ld(col_y + min(j_first + lane, d.dst_w - 1));
+        bc_plane<EXACT, 1>(t.y[id.frame] - ym, ym, d.pitch_y, d.src_h, d.src_w, ax, 0, sparse, dma, ring, hcol, yt, lane, nrows, row_y + i_first, d.bc_npy);
     }
     if constexpr (!kLumaOnly<OUT>) { // chroma: lane = (pair column, component); taps in pair units, 2 bytes apart
-        const BcAxis ax = bc_axis<INT>(min((j_first >> 1) + (lane >> 1), (d.dst_w >> 1) - 1), d.xr, d.src_w, d.src_w >> 1);
-        bc_plane<INT, 2>(t.uv[id.frame] - uvm, uvm, d.pitch_uv, d.src_h >> 1, ax, lane & 1, sparse, huv, uvt, lane, ncrows, 32, rw);
+        const BcEntry ax = bc_ld(col_c + min((j_first >> 1) + (lane >> 1), (d.dst_w >> 1) - 1));
+        bc_plane<EXACT, 2>(t.uv[id.frame] - uvm, uvm, d.pitch_uv, d.src_h >> 1, d.src_w, ax, lane & 1, sparse, dma, ring, hcol, uvt, lane, ncrows, row_c + (i_first >> 1), d.bc_npc);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -293,35 +386,101 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
 #pragma unroll
         for (int r = 0; r < PXH; r++) {
             const uint32_t v = *(const uint32_t *)(yt + (r0 + r) * 64 + lx * PXW);
-            Yf[r][0] = __builtin_amdgcn_cvt_f32_ubyte0(v);
-            Yf[r][1] = __builtin_amdgcn_cvt_f32_ubyte1(v);
-            Yf[r][2] = __builtin_amdgcn_cvt_f32_ubyte2(v);
-            Yf[r][3] = __builtin_amdgcn_cvt_f32_ubyte3(v);
+            Yf[r][0] = ub0(v);
+            Yf[r][1] = ub1(v);
+            Yf[r][2] = ub2(v);
+            Yf[r][3] = ub3(v);
         }
         if constexpr (!kLumaOnly<OUT>) {
             const uint32_t c = *(const uint32_t *)(uvt + (r0 >> 1) * 64 + lx * PXW);
-            Uf[0] = __builtin_amdgcn_cvt_f32_ubyte0(c);
-            Vf[0] = __builtin_amdgcn_cvt_f32_ubyte1(c);
-            Uf[1] = __builtin_amdgcn_cvt_f32_ubyte2(c);
-            Vf[1] = __builtin_amdgcn_cvt_f32_ubyte3(c);
+            Uf[0] = ub0(c);
+            Vf[0] = ub1(c);
+            Uf[1] = ub2(c);
+            Vf[1] = ub3(c);
         }
         color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
     }
 }
 
-hipError_t launch_bicubic_cols(OutKind out, bool integer, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
+int bicubic_cols_rows_padded(int n) { return ((n + 3) & ~3) + 4; }
+
+// The request's tables, evaluated on the host with the functions the kernels of rounds 1 / 2 evaluated per tile
+// (bicubic_axis, bicubic_offsets, cubic_coeffs: plain IEEE operations, identical on host and device) and cached in the
+// context: (dst_w + dst_w / 2) column records of 32 bytes + 7 ints per row -- ~240 KiB for a 4K output.
+const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool may_build) {
+    GeoCache *cache = d.geo_cache;
+    if (!cache) return nullptr;
+    GeoKey key;
+    memset(&key, 0, sizeof(key));
+    uint32_t xb, yb;
+    memcpy(&xb, &d.xr, 4);
+    memcpy(&yb, &d.yr, 4);
+    const int kv[16] = { 2 /* kind: BICUBIC tables */, d.src_w, d.src_h, d.dst_w, d.dst_h, (int)xb, (int)yb, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    memcpy(key.v, kv, sizeof(kv));
+    std::lock_guard<std::mutex> lk(cache->mu);
+    auto it = cache->map.find(key);
+    if (it == cache->map.end()) {
+        if (!may_build || cache->map.size() >= 1024) return nullptr;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+        std::vector<uint8_t> buf;
+        auto append = [&](const void *p, size_t n) {
+            const size_t at = buf.size();
+            buf.resize(at + n);
+            memcpy(buf.data() + at, p, n);
+        };
+        for (int j = 0; j < d.dst_w; j++) { // luma columns, then chroma pair columns: records of 32 bytes
+            const BcEntry e = bc_axis(j, d.xr, d.src_w, d.src_w);
+            append(&e, sizeof(e));
+        }
+        for (int j = 0; j < (d.dst_w >> 1); j++) {
+            const BcEntry e = bc_axis(j, d.xr, d.src_w, d.src_w >> 1);
+            append(&e, sizeof(e));
+        }
+        auto rows_soa = [&](int n, int tap_limit) { // seven int arrays of np entries (rows past the last repeat it)
+            const int np = bicubic_cols_rows_padded(n);
+            std::vector<int> a((size_t)7 * np, 0);
+            for (int i = 0; i < np; i++) {
+                const BcEntry e = bc_axis(i < n ? i : n - 1, d.yr, d.src_h, tap_limit);
+                int wbits;
+                memcpy(&wbits, &e.w, 4);
+                const int v[7] = { e.ws, (int)e.sel, e.l0, e.l1, e.l2, e.bias, wbits };
+                for (int f = 0; f < 7; f++) a[(size_t)f * np + i] = v[f];
+            }
+            append(a.data(), a.size() * sizeof(int));
+        };
+        rows_soa(d.dst_h, d.src_h);
+        rows_soa(d.dst_h >> 1, d.src_h >> 1);
+        GeoEntry e;
+        if (hipMalloc((void **)&e.dev, buf.size()) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemcpy(e.dev, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(e.dev);
+            return nullptr;
+        }
+        it = cache->map.emplace(key, e).first;
+    }
+    return (const BcEntry *)it->second.dev;
+}
+
+hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block(MAX_THREADS);
     if (info) {
-        info->kernel = integer ? "vpp_bicubic_cols_kernel<OUT, true>" : "vpp_bicubic_cols_kernel<OUT, false>";
+        info->kernel = exact ? "vpp_bicubic_cols_kernel<OUT, true>" : "vpp_bicubic_cols_kernel<OUT, false>";
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         return hipSuccess;
     }
+    if (!d.bc_tab) return hipErrorInvalidValue;
     switch (out) {
-#define TSVPP_BC(O)                                                                                                \
-    case O:                                                                                                        \
-        if (integer) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true>), grid, block, lds_bytes, stream, d, t);  \
-        else hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false>), grid, block, lds_bytes, stream, d, t);         \
+#define TSVPP_BC(O)                                                                                               \
+    case O:                                                                                                       \
+        if (exact) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true>), grid, block, lds_bytes, stream, d, t);  \
+        else hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false>), grid, block, lds_bytes, stream, d, t);       \
         break;
         TSVPP_BC(O_U8_PLANAR) TSVPP_BC(O_U8_MERGED) TSVPP_BC(O_F32_PLANAR) TSVPP_BC(O_F32_MERGED) TSVPP_BC(O_NV12_U8)
         TSVPP_BC(O_NV12_F32) TSVPP_BC(O_Y800_U8) TSVPP_BC(O_Y800_F32) TSVPP_BC(O_HSV_F32)

@@ -754,18 +754,6 @@ static bool geo_tables_host(bool areaup, const LaunchDesc &d, GeoHost &g) {
     return true;
 }
 
-struct GeoKey {
-    int v[16];
-    bool operator<(const GeoKey &o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
-};
-struct GeoEntry {
-    uint8_t *dev = nullptr; // one allocation: tx | ty | col | row (null: the request is not eligible)
-    size_t off_ty = 0, off_col = 0, off_row = 0;
-};
-struct GeoCache {
-    std::mutex mu;
-    std::map<GeoKey, GeoEntry> map;
-};
 GeoCache *geo_cache_create() { return new GeoCache(); }
 void geo_cache_destroy(GeoCache *c) {
     if (!c) return;

@@ -90,7 +90,7 @@ __device__ __forceinline__ f2 bilerp2(f2 A, f2 B, f2 C, f2 D, f2 wx, f2 omx, f2 
 
 // Keys cubic, a = -0.75 (src/Resize.cu:45-50).  pow(w,2), pow(w,3) are the exact square and the
 // correctly rounded cube: w has <= 24 significant bits (oracle/pow_pin.c).
-__device__ __forceinline__ void cubic_coeffs(double w, double c[4]) {
+__host__ __device__ __forceinline__ void cubic_coeffs(double w, double c[4]) {
     const double a = -0.75;
     double w2 = w * w, w3 = w2 * w;
     c[0] = (a * w - (2 * a) * w2) + a * w3;
@@ -162,7 +162,7 @@ __device__ __forceinline__ f2 cubic4_pair(float w0, float w1, const float c0[4],
 
 // Tap offsets with the reference's edge rule (src/Resize.cu:32-43): the +1 AND +2 taps collapse
 // onto the centre when either would leave the plane; the -1 tap collapses at the low edge.
-__device__ __forceinline__ void bicubic_offsets(int p, int step, int limit, int &lo, int &hi) {
+__host__ __device__ __forceinline__ void bicubic_offsets(int p, int step, int limit, int &lo, int &hi) {
     hi = step;
     lo = step;
     if (p + step >= limit) hi = 0;

@@ -3,6 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
 
 #include "tsvpp.h"
 
@@ -32,7 +36,18 @@ struct AreaQRow {
     int32_t pad;
 };
 
-struct GeoCache; // host side: device-resident geometry tables of the 2x2-tap kernel (vpp_bilinear.hip)
+struct GeoCache; // host side: device-resident, host-built tables per request geometry (vpp_bilinear.hip, vpp_bicubic_cols.hip)
+
+// One output column / row of a BICUBIC request (vpp_bicubic_cols.hip), evaluated once per request on the host: first sample of the
+// 4-sample window, tap selector (byte k = offset of tap k from the window start: the reference's edge rule), largest tap offset,
+// the weight, and the Keys coefficients quantised to 2^-22 as three planes of signed base-256 digits (digit of tap k in byte k).
+struct BcEntry {
+    int ws;
+    uint32_t sel;
+    int l0, l1, l2, bias;
+    float w;
+    int maxoff;
+};
 
 struct LaunchDesc {
     // logical source = the crop box if crop is active, else the whole frame; the frame
@@ -101,11 +116,34 @@ struct LaunchDesc {
     const int4 *geo_tx, *geo_ty;
     const uint4 *geo_col, *geo_row;
     int geo_pref, geo, geo_build;
+    // BICUBIC with one wave per tile and one lane per output column (vpp_bicubic_cols.hip): allowed (TSVPP_BICUBIC_COLS: 1 = non-dyadic
+    // weights, 2 = every BICUBIC request) / chosen by launch_fused (1 float, 2 integer arithmetic); bc_rows: forced tile height
+    // (TSVPP_BICUBIC_ROWS, 0 = automatic); bc_sparse: the H plane holds the four taps of each output row (vertical ratio >= 4);
+    // bc_dma_pref / bc_dma: source rows through a wave-private LDS-DMA ring (TSVPP_BICUBIC_DMA; horizontal ratios below 3.8) instead of
+    // per-lane loads; bc_ring_bytes: that ring; bc_wave_bytes: LDS bytes of one wave (ring + H plane with column stride hcs_y + result tiles)
+    int bicubic_cols_pref, bicubic_cols, bc_rows, bc_sparse, bc_wave_bytes, bc_dma_pref, bc_dma, bc_ring_bytes;
+    // luma columns [dst_w] | chroma pair columns [dst_w / 2] as BcEntry records, then the rows as seven int arrays each (ws, sel, l0,
+    // l1, l2, bias, w: a wave reads four consecutive rows of one array with ONE scalar load): luma rows, chroma rows; bc_npy / bc_npc =
+    // the padded array lengths (rows rounded up to a multiple of 4, + 4)
+    const BcEntry *bc_tab;
+    int bc_npy, bc_npc;
     int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
     GeoCache *geo_cache;
 };
 
-// Device-resident geometry tables, one set per (request geometry, tile shape); owned by a context, freed with it.
+// Device-resident geometry tables, one set per (kind, request geometry, tile shape); owned by a context, freed with it.
+struct GeoKey {
+    int v[16];
+    bool operator<(const GeoKey &o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+struct GeoEntry {
+    uint8_t *dev = nullptr; // one allocation (null: the request is not eligible)
+    size_t off_ty = 0, off_col = 0, off_row = 0;
+};
+struct GeoCache {
+    std::mutex mu;
+    std::map<GeoKey, GeoEntry> map;
+};
 GeoCache *geo_cache_create();
 void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has selected the device
 
@@ -133,6 +171,12 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, c
 // Integer BICUBIC kernel for dyadic weights (vpp_bicubic_int.hip): LDS bytes it needs beyond the staged planes, launch.
 size_t bicubic_int_table_bytes(int tw, int th, int rows_y, int rows_uv, int hcs_y, int hcs_uv);
 hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
+
+// BICUBIC, one wave per tile, one lane per output column, no staging (vpp_bicubic_cols.hip).
+hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
+// its per-request tables: looked up in / built into the context's cache (never while `stream` is capturing); null if unavailable
+const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool may_build);
+int bicubic_cols_rows_padded(int n); // length of one row array for n rows
 
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
 hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);

@@ -1301,6 +1301,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, false, d, t, grid.x, lds_bytes, stream, info);
         }
     } else if constexpr (MODE == M_BICUBIC) {
+        if (d.bicubic_cols) return launch_bicubic_cols((OutKind)OUT, d.bicubic_cols == 2, d, t, lds_bytes, stream, info);
         if (staged && d.bicubic_int) return launch_bicubic_int((OutKind)OUT, d, t, lds_bytes, stream, info);
         if (staged) {
             if (d.bicubic_sep) TSVPP_LAUNCH("vpp_bicubic_sep_kernel<OUT>", (vpp_bicubic_sep_kernel<OUT>), grid, block, lds_bytes);
@@ -1541,6 +1542,57 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     } else {
         d.point_kind = PK_NONE;
     }
+    // BICUBIC, any ratio: one wave per 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane
+    // (vpp_bicubic_cols.hip).  Tile height R (8 .. 32 output rows): the tallest one whose four waves' LDS fits the budget while the
+    // launch still has >= 4 waves per SIMD -- a taller tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter
+    // one keeps more waves in flight.
+    d.bicubic_cols = 0;
+    d.bc_sparse = 0;
+    d.bc_dma = 0;
+    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && (d.bicubic_cols_pref == 2 || !(d.w_dyadic && d.bicubic_int_pref))) {
+        const bool sparse = d.yr >= 4.0f;
+        const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
+        // LDS-DMA ring: one global_load_lds_dword instruction fetches a row segment of <= 64 dwords (64 columns at ratio xr + window + misalignment)
+        const int nd_max = ((int)((double)d.xr * 63.0) + 2 + 6 + 1 + 6) / 4 + 1;
+        const bool dma = d.bc_dma_pref && nd_max <= 64;
+        const int ring_bytes = dma ? 16 * 4 * nd_max + 16 : 0;
+        auto col_stride = [&](int nout) { // bytes of one H-plane column: its dwords + one (phase 2 reads dword pairs), an odd number of them
+            const int rows = sparse ? 4 * nout : (int)((double)d.yr * (nout - 1)) + 6;
+            return 4 * ((((rows + 3) >> 2) + 1) | 1);
+        };
+        auto wave_bytes_of = [&](int r) { return ring_bytes + 64 * (col_stride(r) + r + r / 2); };
+        int best_r = 0;
+        for (int r = 32; r >= 8 && !best_r; r -= 8) {
+            const bool forced = d.bc_rows == r;
+            if (d.bc_rows >= 8 && d.bc_rows <= 32 && (d.bc_rows & 7) == 0 && !forced) continue;
+            const long waves = (long)((d.dst_w + 63) / 64) * ((d.dst_h + r - 1) / r) * d.n_frames;
+            if (4 * wave_bytes_of(r) > 64 * 1024) continue;
+            if (forced || r == 8 || (4 * (size_t)wave_bytes_of(r) <= kLdsBudget * 2 / 3 && waves >= 16L * d.num_cus)) best_r = r;
+        }
+        // the request's column / row tables (host-built, cached in the context): a real launch -- and the dry run of
+        // tsvpp_prepare_batch -- looks them up or builds them; while the stream is capturing and they do not exist yet the
+        // request takes the generic path below
+        if (best_r && (!info || d.geo_build)) {
+            d.bc_tab = bicubic_cols_tables(d, stream, true);
+            if (!d.bc_tab) best_r = 0;
+        }
+        if (best_r) {
+            d.bicubic_cols = exact ? 2 : 1;
+            d.bc_sparse = sparse ? 1 : 0;
+            d.bc_dma = dma ? 1 : 0;
+            d.bc_ring_bytes = ring_bytes;
+            d.bc_npy = bicubic_cols_rows_padded(d.dst_h);
+            d.bc_npc = bicubic_cols_rows_padded(d.dst_h >> 1);
+            d.hcs_y = col_stride(best_r);
+            d.hcs_uv = d.hcs_y;
+            d.bc_wave_bytes = wave_bytes_of(best_r);
+            lds_bytes = 4 * (size_t)d.bc_wave_bytes;
+            d.tx = 16; // colour phase: a wave = 16 x 4 thread tiles per 8-row slab (MergedRun: runs of 16 lanes)
+            d.ty = 4;
+            d.rpt = best_r / 8;
+            d.dma = 0;
+        }
+    }
     // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
     // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
     // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
@@ -1548,7 +1600,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && ratio_area >= 30.0f);
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather) {
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.bicubic_cols) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
@@ -1665,6 +1717,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         }
     }
     if (!staged) d.dma = 0;
+    const size_t bc_lds = lds_bytes;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
     // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
@@ -1698,7 +1751,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         }
     }
     d.tx_shift = slot_shift_for(d.tx);
-    const int tile_w = d.tx * (d.r32 ? 8 : PXW), tile_h = d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
+    if (d.r32) d.bicubic_cols = 0;
+    if (d.bicubic_cols) lds_bytes = bc_lds;
+    const int tile_w = d.bicubic_cols ? 256 : d.tx * (d.r32 ? 8 : PXW), tile_h = d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt; // bicubic_cols: four waves side by side
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
@@ -1744,6 +1799,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     td.dma = 0;
     td.point_kind = PK_NONE; // the generic samplers give the point samplers' values (all weights are zero)
     td.area_direct = 0;
+    td.bicubic_cols = 0;
     td.tiles_x = 1;
     td.tiles_y = (d.dst_h + td.ty * PXH - 1) / (td.ty * PXH);
     const long rows = (long)td.tiles_y * td.n_frames;
