@@ -201,7 +201,6 @@ struct tsvpp_ctx {
     // (measured after its VGPR fix: 2x 501 k vs 368 k fps, 3x 743 k vs 621 k, 4x 162 k vs 251 k)
     float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
     float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
-    int bicubic_sep = 1;            // TSVPP_BICUBIC_SEP
     int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
     int bilinear_int = 1;           // TSVPP_BILINEAR_INT: integer thread tile of the 2x2-tap kernel for dyadic weights
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
@@ -217,7 +216,7 @@ struct tsvpp_ctx {
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
     int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
     int r32 = 1;                    // TSVPP_R32: streaming kernel for BILINEAR at exactly 3 : 2 with uint8 outputs
-    int bicubic_cols = 2;           // TSVPP_BICUBIC_COLS: wave-per-tile BICUBIC kernel (1: non-dyadic weights only, 2: every BICUBIC request, 0: off)
+    int bicubic_cols = 1;           // TSVPP_BICUBIC_COLS: wave-per-tile BICUBIC kernel (1: what the integer kernel does not take, 2: every BICUBIC request, 0: off)
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
@@ -322,7 +321,6 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
-    if (const char *e = std::getenv("TSVPP_BICUBIC_SEP")) ctx->bicubic_sep = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
@@ -367,7 +365,6 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
     d.area_direct_fmin = ctx->area_direct_fmin;
-    d.bicubic_sep = ctx->bicubic_sep;
     d.bicubic_int_pref = ctx->bicubic_int;
     d.bicubic_cols_pref = ctx->bicubic_cols;
     d.bc_rows = ctx->bicubic_rows;

@@ -51,7 +51,7 @@ namespace tsvpp {
 // at wave-uniform addresses (the rows' entries) become scalar loads (s_load_dwordx8: no VALU, no VGPRs).
 typedef const __attribute__((address_space(4))) BcEntry *BcTab;
 typedef int bc_i4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) int *BcRows;     // seven arrays of `np` ints: ws | sel | l0 | l1 | l2 | bias | w
+typedef const __attribute__((address_space(4))) int *BcRows;     // row blocks (see bc_row_ws)
 typedef const __attribute__((address_space(4))) bc_i4 *BcRows4;
 __device__ __forceinline__ BcTab bc_const(const BcEntry *p) { return (BcTab)(uintptr_t)p; }
 __device__ __forceinline__ BcEntry bc_ld(BcTab p) {
@@ -65,7 +65,6 @@ typedef uint32_t u32x3a4c __attribute__((ext_vector_type(3), aligned(4)));
 
 constexpr int BC_SHIFT = 22;             // coefficient scale 2^22
 constexpr int BC_TIE = 560;              // tie zone in units of 2^-22 (error bound 510)
-constexpr int BC_RING_ROWS = 16;         // rows of the LDS-DMA ring (four groups of four)
 
 // byte k of a dword as a float: the compiler selects v_cvt_f32_ubyte<k>
 __device__ __forceinline__ float ub0(uint32_t v) { return (float)(v & 255u); }
@@ -113,10 +112,11 @@ static BcEntry bc_axis(int idx, float ratio, int clamp_limit, int tap_limit) {
 // 2^22 x the 4-tap sum over the packed taps (tap k in byte k) + 2^21: the value is clamp(that >> 22, 0, 255)
 __device__ __forceinline__ int bc_isum(uint32_t taps, int l0, int l1, int l2, int bias) {
     const uint32_t x = taps ^ 0xff0000ffu; // taps 0 and 3 complemented: their coefficients are <= 0
-    const uint32_t s0 = __builtin_amdgcn_udot4(x, (uint32_t)l0, (uint32_t)bias, false);
-    const uint32_t s1 = __builtin_amdgcn_udot4(x, (uint32_t)l1, 0u, false);
+    // ((d2 << 8) + d1 << 8) + d0 + bias as a chain through the dot products' accumulator inputs: dot, shift, dot, shift-add, dot
+    // (written as sums the compiler re-associates it into two shifts + v_add3 and a separate bias add)
     const uint32_t s2 = __builtin_amdgcn_udot4(x, (uint32_t)l2, 0u, false);
-    return (int)((((s2 << 8) + s1) << 8) + s0);
+    const uint32_t s1 = __builtin_amdgcn_udot4(x, (uint32_t)l1, s2 << 8, false);
+    return (int)__builtin_amdgcn_udot4(x, (uint32_t)l0, (s1 << 8) + (uint32_t)bias, false);
 }
 // distance-to-tie key: small (< 2 BC_TIE << 10) iff the sum is within BC_TIE units of a rounding tie
 __device__ __forceinline__ uint32_t bc_tie_key(int s) { return (uint32_t)(s + BC_TIE) << (32 - BC_SHIFT); }
@@ -166,90 +166,84 @@ __device__ __forceinline__ uint32_t bc_taps(const uint32_t (&dw)[NDW], uint32_t 
     }
 }
 
+// Row parameters (wave-uniform: scalar loads).  Rows come in blocks of four: 32 ints = [ws x4 | sel x4 | l0 x4 | l1 x4 | l2 x4 |
+// bias x4 | w x4 | pad x4], so that ONE base address serves a whole phase-2 step.  `rb` = the block of the tile's first row.
+__device__ __forceinline__ int bc_row_ws(BcRows rb, int i) { return rb[(i >> 2) * 32 + (i & 3)]; }
+__device__ __forceinline__ uint32_t bc_row_sel(BcRows rb, int i) { return (uint32_t)rb[(i >> 2) * 32 + 4 + (i & 3)]; }
+
 // One plane (luma: STEP 1, lane = column; chroma: STEP 2, lane = (pair column, component)) through phases 1 and 2.
-// ax: the lane's column; rows: the tile's first row entry (wave-uniform pointer: scalar loads); hcol: this lane's column of
-// the wave's H plane; ring: the wave's LDS-DMA ring (DMA mode); res: the wave's result tile (row-major, 64 bytes per row).
-template <bool EXACT, int STEP>
-__device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int pitch, int rows_in_plane, int row_bytes, const BcEntry &ax, int comp,
-                                         bool sparse, bool dma, uint8_t *ring, uint8_t *hcol, uint8_t *res, int lane, int nout, BcRows rows, int np) {
+// ax: the lane's column; rb: the tile's first row block; hcol: this lane's column of the wave's H plane; ring: the wave's
+// LDS-DMA ring (DMA mode); res: the wave's result tile (row-major, 64 bytes per row).
+template <bool EXACT, bool SPARSE, int STEP>
+__device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, int rows_in_plane, int row_bytes, const BcEntry &ax, int comp, bool dma, int lanes_per_row,
+                                         uint8_t *ring, uint8_t *hcol, uint8_t *res, int lane, int nout, BcRows rb) {
     constexpr int NDW = STEP == 1 ? 2 : 3;
-    const int ylo = rows[0], yhi = min(rows[nout - 1] + 3, rows_in_plane - 1); // dense: every row from the first window's start to the last window's end
-    const int ng = sparse ? nout : ((yhi - ylo + 1 + 3) >> 2);
-    // source rows of group g: the four taps of output row g in tap order (sparse), or four consecutive rows (dense)
-    auto group_rows = [&](int g, int (&rr)[4]) {
-        if (sparse) {
-            const int ws = rows[g];
-            const uint32_t sel = (uint32_t)rows[np + g];
-#pragma unroll
-            for (int k = 0; k < 4; k++) rr[k] = ws + (int)((sel >> (8 * k)) & 255u);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) rr[k] = min(ylo + 4 * g + k, yhi);
-        }
-    };
+    // the plane pointer rounded down to 16 bytes (wave-uniform) + the bytes it was rounded by: every offset below is >= 0
+    const uint32_t pm = (uint32_t)((uintptr_t)frame_plane & 15);
+    const uint8_t *plane = frame_plane - pm;
+    const int ylo = bc_row_ws(rb, 0), yhi = min(bc_row_ws(rb, nout - 1) + 3, rows_in_plane - 1); // dense: from the first window's start to the last window's end
+    const int ng = SPARSE ? nout : ((yhi - ylo + 1 + 3) >> 2);
     const int xb = STEP * ax.ws + comp; // the lane's window start, byte column of the plane
     const uint32_t tapsel = STEP == 1 ? ax.sel : ax.sel + ax.sel;
-    const bool aligned = (pitch & 3) == 0; // every row then has the same misalignment: lane addresses and selectors are loop-invariant
-    // ---- phase 1: H of every needed source row of this lane's column, four rows per dword
-    if (dma) {
-        // the wave's row segment: bytes [xb0, xbl + 3 STEP] of a row, fetched as nd aligned dwords by lanes 0 .. nd - 1
-        const int xb0 = __builtin_amdgcn_readlane(xb, 0), xbl = __builtin_amdgcn_readlane(xb, 63);
-        const int nd = (xbl + 3 * STEP - xb0 + 1 + 3 + 3) >> 2;
-        const int rowb = 4 * nd;
-        const uint32_t lane4 = 4u * (uint32_t)lane;
-        auto issue = [&](int g) {
-            int rr[4];
-            group_rows(g, rr);
-            if (lane < nd) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t r0 = (uint32_t)rr[k] * (uint32_t)pitch + pm;
-                    const uint32_t seg = (r0 + (uint32_t)xb0) & ~3u, seg_last = (r0 + (uint32_t)row_bytes - 1u) & ~3u; // never past the row's last dword
-                    const uint8_t *src = plane + min(seg + lane4, seg_last);
-                    uint8_t *dst = ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb; // wave-uniform
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-                }
-            }
-        };
-        const int npre = min(BC_RING_ROWS / 4, ng);
-        for (int g = 0; g < npre; g++) issue(g);
-        // aligned: the lane's dword offset inside a ring row and its shifted selector, once
-        const uint32_t a_c = (uint32_t)(xb - xb0) + ((pm + (uint32_t)xb0) & 3u);
+    // ---- phase 1: H of every needed source row of this lane's column, four rows per dword of the column
+    if (dma && (pitch & 15) == 0) {
+        // LDS-DMA: ONE global_load_lds_dwordx4 fetches a BATCH of row segments -- L lanes per row, 16 bytes each, L = the 16-byte chunks
+        // a segment needs at this ratio (host: 64 columns x ratio + window + misalignment), 4 * floor(16 / L) rows per batch (4, 8 or
+        // 16: one, two or four groups) -- into a ring of three batches of 1 KiB.  Lane addresses are loop-invariant up to the batch's
+        // first row.  (The first version fetched 256 bytes per row whatever the ratio: 2.5 x the needed bytes at ratio 1.5, and the
+        // launch ran 40 us longer than with its reads served from cache.)
+        const int L = SPARSE ? 16 : lanes_per_row, rpb = SPARSE ? 4 : 4 * (16 / L), gpb = rpb >> 2; // rows, groups per batch
+        const int xb0 = __builtin_amdgcn_readlane(xb, 0);
+        const uint32_t seg0 = (pm + (uint32_t)xb0) & ~15u;           // the segment's first 16-byte chunk (byte column from `plane`)
+        const uint32_t a_c = (uint32_t)(xb - xb0) + ((pm + (uint32_t)xb0) & 15u); // the lane's window start inside a ring row
         const uint32_t al_c = a_c & ~3u, sh_c = a_c & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
-        for (int g = 0; g < ng; g++) {
-            // group g has landed when at most the later groups' loads are outstanding (4 per group)
-            const int later = min(BC_RING_ROWS / 4 - 1, ng - 1 - g);
-            if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t tp[4];
-            if (aligned) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t *p = (const uint32_t *)(ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb + al_c);
-                    uint32_t dw[NDW];
-#pragma unroll
-                    for (int q = 0; q < NDW; q++) dw[q] = p[q];
-                    tp[k] = bc_taps<STEP, NDW>(dw, sh_c, selx_c);
-                }
+        const uint32_t last_chunk = ((uint32_t)(rows_in_plane - 1) * (uint32_t)pitch + pm + (uint32_t)row_bytes - 1u) & ~15u; // the plane's last valid chunk
+        const int lrow = (lane * (65536 / L + 1)) >> 16, lchunk = lane - lrow * L; // lane / L, lane % L (L <= 16, lane < 64: exact)
+        const bool lane_on = lrow < rpb;
+        const uint32_t lconst = seg0 + 16u * (uint32_t)lchunk + (SPARSE ? 0u : (uint32_t)lrow * (uint32_t)pitch);
+        const int rstride = 16 * L; // ring row pitch
+        const int nb = (ng + gpb - 1) / gpb;
+        auto issue = [&](int bt, int slot) {
+            uint32_t voff;
+            if constexpr (SPARSE) { // one output row per batch: lane group k fetches its tap k
+                const uint32_t tapoff = __builtin_amdgcn_ubfe(bc_row_sel(rb, bt), 8u * (uint32_t)lrow, 8u);
+                voff = ((uint32_t)bc_row_ws(rb, bt) + tapoff) * (uint32_t)pitch + lconst;
             } else {
-                int rr[4];
-                group_rows(g, rr);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t shr = ((uint32_t)rr[k] * (uint32_t)pitch + pm + (uint32_t)xb0) & 3u; // the segment's misalignment (uniform)
-                    const uint32_t a = (uint32_t)(xb - xb0) + shr;
-                    const uint32_t *p = (const uint32_t *)(ring + ((4 * g + k) & (BC_RING_ROWS - 1)) * rowb + (a & ~3u));
-                    uint32_t dw[NDW];
-#pragma unroll
-                    for (int q = 0; q < NDW; q++) dw[q] = p[q];
-                    tp[k] = bc_taps<STEP, NDW>(dw, a & 3u, STEP == 1 ? tapsel + rep4(a & 3u) : tapsel);
-                }
+                voff = (uint32_t)(ylo + rpb * bt) * (uint32_t)pitch + lconst; // rows past yhi are real rows of the plane (or clamped below): never used
             }
-            if (g + BC_RING_ROWS / 4 < ng) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the ring slots of group g have been read
-                issue(g + BC_RING_ROWS / 4);
+            voff = min(voff, last_chunk);
+            uint8_t *dst = ring + slot * 1024; // wave-uniform
+            if (lane_on)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        };
+        issue(0, 0);
+        if (nb > 1) issue(1, 1);
+        if (nb > 2) issue(2, 2);
+        int slot = 0, bt = 0, gin = 0; // ring slot and index of the current batch, group inside it
+        for (int g = 0; g < ng; g++) {
+            if (gin == 0) { // batch bt has landed when at most the later batches' loads are outstanding (one per batch)
+                if (bt + 2 < nb) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (bt + 1 < nb) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const uint8_t *p0 = ring + slot * 1024 + 4 * gin * rstride + al_c;
+            uint32_t tp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t *p = (const uint32_t *)(p0 + k * rstride);
+                uint32_t dw[NDW];
+#pragma unroll
+                for (int q = 0; q < NDW; q++) dw[q] = p[q];
+                tp[k] = bc_taps<STEP, NDW>(dw, sh_c, selx_c);
+            }
+            if (++gin == gpb) { // the batch's last group: its slot is free once the reads above have returned
+                if (bt + 3 < nb) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue(bt + 3, slot);
+                }
+                gin = 0;
+                bt++;
+                slot = slot == 2 ? 0 : slot + 1;
             }
             int s[4];
 #pragma unroll
@@ -257,70 +251,105 @@ __device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int 
             *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
         }
     } else {
-        // direct mode: every lane loads the NDW dwords around its own window, one group ahead
+        // direct mode (horizontal ratios >= 3.7, or a pitch that is no multiple of 16): every lane loads the NDW dwords around its own
+        // window.  Groups that do not touch the plane's last row (all but the bottom tiles' last) run software-pipelined, one group
+        // ahead, with unconditional vector loads (a fixed number per group: the compiler's wait counts stay exact); the others load
+        // dword by dword and never read past the last needed byte's dword.
         const uint32_t xoff = pm + (uint32_t)xb;
         const int xneed = STEP * ax.maxoff;
+        const bool aligned = (pitch & 3) == 0; // every row then has the same misalignment: lane offsets and selectors are loop-invariant
         const uint32_t sh_c = xoff & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
-        uint32_t cur[4][NDW], csh[4];
-        auto fetch = [&](int g, uint32_t (&dw)[4][NDW], uint32_t (&sh)[4]) {
+        auto group_rows = [&](int g, int (&rr)[4]) {
+            if constexpr (SPARSE) { // the four taps of output row g, in tap order
+                const int ws = bc_row_ws(rb, g);
+                const uint32_t sel = bc_row_sel(rb, g);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rr[k] = ws + (int)((sel >> (8 * k)) & 255u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) rr[k] = min(ylo + 4 * g + k, yhi);
+            }
+        };
+        auto row_ptr = [&](int row, uint32_t &sh) { // the aligned dword holding the lane's window start in `row`, its byte offset there
+            const uint32_t a = (uint32_t)row * (uint32_t)pitch + xoff; // aligned: a & 3 == sh_c whatever the row
+            sh = aligned ? sh_c : (a & 3u);
+            // aligned: (row * pitch + xoff) & ~3 == row * pitch + (xoff & ~3): a wave-uniform row pointer + a loop-invariant lane offset
+            return aligned ? (const uint32_t *)(plane + (size_t)((uint32_t)row * (uint32_t)pitch) + (xoff & ~3u)) : (const uint32_t *)(plane + (a & ~3u));
+        };
+        auto fetch = [&](int g, uint32_t (&dw)[4][NDW], uint32_t (&sh)[4]) { // rows below the plane's last: the bytes after the window belong to the plane
             int rr[4];
             group_rows(g, rr);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t a = (uint32_t)rr[k] * (uint32_t)pitch + xoff; // aligned: a & 3 == sh_c whatever the row
-                sh[k] = a & 3u;
-                // aligned: (row * pitch + xoff) & ~3 == row * pitch + (xoff & ~3): a wave-uniform row pointer + a loop-invariant lane offset
-                const uint32_t *p = aligned ? (const uint32_t *)(plane + (size_t)((uint32_t)rr[k] * (uint32_t)pitch) + (xoff & ~3u))
-                                            : (const uint32_t *)(plane + (a & ~3u));
-                if (rr[k] < rows_in_plane - 1) { // not the plane's last row: the bytes after the window belong to the plane
-                    if constexpr (NDW == 2) {
-                        const u32x2a4c v = *(const u32x2a4c *)p;
-                        dw[k][0] = v.x; dw[k][1] = v.y;
-                    } else {
-                        const u32x3a4c v = *(const u32x3a4c *)p;
-                        dw[k][0] = v.x; dw[k][1] = v.y; dw[k][2] = v.z;
-                    }
-                } else { // a dword past the last needed byte is re-pointed at the first: nothing is read beyond the last needed byte's dword
-                    const int hi = (int)sh[k] + xneed;
-#pragma unroll
-                    for (int q = 0; q < NDW; q++) dw[k][q] = p[(4 * q <= hi) ? q : 0];
+                const uint32_t *p = row_ptr(rr[k], sh[k]);
+                if constexpr (NDW == 2) {
+                    const u32x2a4c v = *(const u32x2a4c *)p;
+                    dw[k][0] = v.x; dw[k][1] = v.y;
+                } else {
+                    const u32x3a4c v = *(const u32x3a4c *)p;
+                    dw[k][0] = v.x; dw[k][1] = v.y; dw[k][2] = v.z;
                 }
             }
         };
-        fetch(0, cur, csh);
-        for (int g = 0; g < ng; g++) {
-            uint32_t nxt[4][NDW] = {}, nsh[4] = {};
-            if (g + 1 < ng) fetch(g + 1, nxt, nsh); // one group ahead
+        auto finish = [&](int g, const uint32_t (&dw)[4][NDW], const uint32_t (&sh)[4]) {
             uint32_t tp[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) tp[k] = aligned ? bc_taps<STEP, NDW>(cur[k], sh_c, selx_c) : bc_taps<STEP, NDW>(cur[k], csh[k], STEP == 1 ? tapsel + rep4(csh[k]) : tapsel);
+            for (int k = 0; k < 4; k++) tp[k] = bc_taps<STEP, NDW>(dw[k], sh[k], aligned ? selx_c : (STEP == 1 ? tapsel + rep4(sh[k]) : tapsel));
             int s[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
             *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
+        };
+        // leading groups whose rows all lie above the plane's last row
+        int ngf;
+        if constexpr (SPARSE) ngf = (bc_row_ws(rb, nout - 1) + 3 < rows_in_plane - 1) ? ng : 0;
+        else ngf = (yhi < rows_in_plane - 1) ? ng : max(min((rows_in_plane - 1 - ylo) >> 2, ng), 0);
+        if (ngf > 0) {
+            uint32_t cur[4][NDW], csh[4];
+            fetch(0, cur, csh);
+            for (int g = 0; g + 1 < ngf; g++) {
+                uint32_t nxt[4][NDW], nsh[4];
+                fetch(g + 1, nxt, nsh); // one group ahead
+                finish(g, cur, csh);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    csh[k] = nsh[k];
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) cur[k][q] = nxt[k][q];
+                }
+            }
+            finish(ngf - 1, cur, csh);
+        }
+        for (int g = ngf; g < ng; g++) {
+            int rr[4];
+            group_rows(g, rr);
+            uint32_t dw[4][NDW], sh[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                csh[k] = nsh[k];
+                const uint32_t *p = row_ptr(rr[k], sh[k]);
+                const int hi = (int)sh[k] + xneed; // a dword past the last needed byte is re-pointed at the first
 #pragma unroll
-                for (int q = 0; q < NDW; q++) cur[k][q] = nxt[k][q];
+                for (int q = 0; q < NDW; q++) dw[k][q] = p[(rr[k] < rows_in_plane - 1 || 4 * q <= hi) ? q : 0];
             }
+            finish(g, dw, sh);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- phase 2: vertical sums, four output rows per step.  The rows' parameters are wave-uniform: ONE scalar load per array
-    // fetches them for the step's four rows (the arrays are padded, so a partial last step reads valid entries it does not store).
+    // ---- phase 2: vertical sums, four output rows per step.  The rows' parameters are wave-uniform: three scalar loads fetch
+    // them for the step's four rows (the table is padded by a block, so a partial last step reads valid entries it does not store).
     for (int i = 0; i < nout; i += 4) {
-        const bc_i4 ws4 = *(BcRows4)(rows + i), sel4 = *(BcRows4)(rows + np + i), a4 = *(BcRows4)(rows + 2 * np + i), b4 = *(BcRows4)(rows + 3 * np + i),
-                    c4 = *(BcRows4)(rows + 4 * np + i), bias4 = *(BcRows4)(rows + 5 * np + i);
+        const BcRows blk = rb + (i >> 2) * 32;
+        const bc_i4 ws4 = *(BcRows4)(blk), sel4 = *(BcRows4)(blk + 4), a4 = *(BcRows4)(blk + 8), b4 = *(BcRows4)(blk + 12), c4 = *(BcRows4)(blk + 16),
+                    bias4 = *(BcRows4)(blk + 20);
         uint32_t tp[4];
         int s[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int off = sparse ? 4 * (i + e) : max(ws4[e] - ylo, 0); // (entries past the tile's last row: clamped into the column)
+            const int off = SPARSE ? 4 * (i + e) : max(ws4[e] - ylo, 0); // (rows past the tile's last one: anywhere inside the column)
             const uint32_t *p = (const uint32_t *)(hcol + (off & ~3));
             const uint32_t win = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off & 3u);
-            tp[e] = __builtin_amdgcn_perm(0u, win, sparse ? 0x03020100u : (uint32_t)sel4[e]);
+            tp[e] = SPARSE ? win : __builtin_amdgcn_perm(0u, win, (uint32_t)sel4[e]);
             s[e] = bc_isum(tp[e], a4[e], b4[e], c4[e], bias4[e]);
         }
         uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
@@ -328,7 +357,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int 
             const uint32_t k0 = bc_tie_key(s[0]), k1 = bc_tie_key(s[1]), k2 = bc_tie_key(s[2]), k3 = bc_tie_key(s[3]);
             if (min(min(k0, k1), min(k2, k3)) < BC_TIE_KEY) { // rarely taken
                 // (four scalar dword loads: ROCm 7.2's clang, given ONE dwordx4 load here, used element 0 for all four weights)
-                const BcRows wp = rows + 6 * np + i;
+                const BcRows wp = blk + 24;
                 if (k0 < BC_TIE_KEY) r = (r & 0xffffff00u) | bc_exact(tp[0], __builtin_bit_cast(float, wp[0]));
                 if (k1 < BC_TIE_KEY) r = (r & 0xffff00ffu) | bc_exact(tp[1], __builtin_bit_cast(float, wp[1])) << 8;
                 if (k2 < BC_TIE_KEY) r = (r & 0xff00ffffu) | bc_exact(tp[2], __builtin_bit_cast(float, wp[2])) << 16;
@@ -342,7 +371,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *plane, uint32_t pm, int 
     }
 }
 
-template <int OUT, bool EXACT>
+template <int OUT, bool EXACT, bool SPARSE>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
     const TileId id = decode_tile(d);
@@ -352,24 +381,23 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
     const int j_first = id.tx * 256 + wave * 64, i_first = id.ty * R;
     if (j_first >= d.dst_w) return; // (no workgroup barrier anywhere in this kernel)
     const int nrows = min(R, d.dst_h - i_first), ncrows = nrows >> 1;
-    const bool sparse = d.bc_sparse != 0, dma = d.bc_dma != 0;
+    const bool dma = d.bc_dma != 0;
 
     // wave-private LDS: DMA ring, H plane (column-major, one column per lane; luma then chroma), result tiles (row-major)
     uint8_t *wl = lds_raw + wave * d.bc_wave_bytes;
     uint8_t *ring = wl, *hcol = wl + d.bc_ring_bytes + lane * d.hcs_y;
     uint8_t *yt = wl + d.bc_ring_bytes + 64 * d.hcs_y, *uvt = yt + 64 * R;
 
-    // the request's tables (host-built): luma columns | chroma pair columns | luma rows | chroma rows
+    // the request's tables (host-built): luma columns | chroma pair columns | luma row blocks | chroma row blocks
     const BcTab col_y = bc_const(d.bc_tab), col_c = col_y + d.dst_w;
-    const BcRows row_y = (BcRows)(col_c + (d.dst_w >> 1)), row_c = row_y + 7 * d.bc_npy;
-    const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
+    const BcRows row_y = (BcRows)(col_c + (d.dst_w >> 1)), row_c = row_y + 32 * d.bc_npy;
     { // luma: lane = column (columns past the frame repeat the last one; never stored)
         const BcEntry ax = bc_ld(col_y + min(j_first + lane, d.dst_w - 1));
-        bc_plane<EXACT, 1>(t.y[id.frame] - ym, ym, d.pitch_y, d.src_h, d.src_w, ax, 0, sparse, dma, ring, hcol, yt, lane, nrows, row_y + i_first, d.bc_npy);
+        bc_plane<EXACT, SPARSE, 1>(t.y[id.frame], d.pitch_y, d.src_h, d.src_w, ax, 0, dma, d.bc_dma, ring, hcol, yt, lane, nrows, row_y + (i_first >> 2) * 32);
     }
     if constexpr (!kLumaOnly<OUT>) { // chroma: lane = (pair column, component); taps in pair units, 2 bytes apart
         const BcEntry ax = bc_ld(col_c + min((j_first >> 1) + (lane >> 1), (d.dst_w >> 1) - 1));
-        bc_plane<EXACT, 2>(t.uv[id.frame] - uvm, uvm, d.pitch_uv, d.src_h >> 1, d.src_w, ax, lane & 1, sparse, dma, ring, hcol, uvt, lane, ncrows, row_c + (i_first >> 1), d.bc_npc);
+        bc_plane<EXACT, SPARSE, 2>(t.uv[id.frame], d.pitch_uv, d.src_h >> 1, d.src_w, ax, lane & 1, dma, d.bc_dma, ring, hcol, uvt, lane, ncrows, row_c + (i_first >> 3) * 32);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -402,7 +430,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
     }
 }
 
-int bicubic_cols_rows_padded(int n) { return ((n + 3) & ~3) + 4; }
+int bicubic_cols_rows_padded(int n) { return (n + 3) / 4 + 1; } // row blocks (of four rows) for n rows: one spare block
 
 // The request's tables, evaluated on the host with the functions the kernels of rounds 1 / 2 evaluated per tile
 // (bicubic_axis, bicubic_offsets, cubic_coeffs: plain IEEE operations, identical on host and device) and cached in the
@@ -438,20 +466,20 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
             const BcEntry e = bc_axis(j, d.xr, d.src_w, d.src_w >> 1);
             append(&e, sizeof(e));
         }
-        auto rows_soa = [&](int n, int tap_limit) { // seven int arrays of np entries (rows past the last repeat it)
-            const int np = bicubic_cols_rows_padded(n);
-            std::vector<int> a((size_t)7 * np, 0);
-            for (int i = 0; i < np; i++) {
+        auto row_blocks = [&](int n, int tap_limit) { // blocks of four rows x eight fields (rows past the last repeat it)
+            const int nb = bicubic_cols_rows_padded(n);
+            std::vector<int> a((size_t)32 * nb, 0);
+            for (int i = 0; i < 4 * nb; i++) {
                 const BcEntry e = bc_axis(i < n ? i : n - 1, d.yr, d.src_h, tap_limit);
                 int wbits;
                 memcpy(&wbits, &e.w, 4);
                 const int v[7] = { e.ws, (int)e.sel, e.l0, e.l1, e.l2, e.bias, wbits };
-                for (int f = 0; f < 7; f++) a[(size_t)f * np + i] = v[f];
+                for (int f = 0; f < 7; f++) a[(size_t)(i >> 2) * 32 + 4 * f + (i & 3)] = v[f];
             }
             append(a.data(), a.size() * sizeof(int));
         };
-        rows_soa(d.dst_h, d.src_h);
-        rows_soa(d.dst_h >> 1, d.src_h >> 1);
+        row_blocks(d.dst_h, d.src_h);
+        row_blocks(d.dst_h >> 1, d.src_h >> 1);
         GeoEntry e;
         if (hipMalloc((void **)&e.dev, buf.size()) != hipSuccess) {
             (void)hipGetLastError();
@@ -469,18 +497,22 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
 
 hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block(MAX_THREADS);
+    const bool sparse = d.bc_sparse != 0;
     if (info) {
-        info->kernel = exact ? "vpp_bicubic_cols_kernel<OUT, true>" : "vpp_bicubic_cols_kernel<OUT, false>";
+        info->kernel = exact ? (sparse ? "vpp_bicubic_cols_kernel<OUT, exact, sparse>" : "vpp_bicubic_cols_kernel<OUT, exact, dense>")
+                             : (sparse ? "vpp_bicubic_cols_kernel<OUT, tie, sparse>" : "vpp_bicubic_cols_kernel<OUT, tie, dense>");
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         return hipSuccess;
     }
     if (!d.bc_tab) return hipErrorInvalidValue;
     switch (out) {
-#define TSVPP_BC(O)                                                                                               \
-    case O:                                                                                                       \
-        if (exact) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true>), grid, block, lds_bytes, stream, d, t);  \
-        else hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false>), grid, block, lds_bytes, stream, d, t);       \
+#define TSVPP_BC(O)                                                                                                               \
+    case O:                                                                                                                       \
+        if (exact && sparse) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true, true>), grid, block, lds_bytes, stream, d, t);   \
+        else if (exact) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true, false>), grid, block, lds_bytes, stream, d, t);       \
+        else if (sparse) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false, true>), grid, block, lds_bytes, stream, d, t);      \
+        else hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false, false>), grid, block, lds_bytes, stream, d, t);                 \
         break;
         TSVPP_BC(O_U8_PLANAR) TSVPP_BC(O_U8_MERGED) TSVPP_BC(O_F32_PLANAR) TSVPP_BC(O_F32_MERGED) TSVPP_BC(O_NV12_U8)
         TSVPP_BC(O_NV12_F32) TSVPP_BC(O_Y800_U8) TSVPP_BC(O_Y800_F32) TSVPP_BC(O_HSV_F32)

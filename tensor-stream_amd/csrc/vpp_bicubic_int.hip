@@ -8,7 +8,7 @@
 //     S = sum_t C_t p_t  with C_t = 16384 c_t (|C_t| <= 18811, fits int16),   value = clamp((S + 8192) >> 14, 0, 255)
 // (S < 0 rounds to <= 0 and clamps to 0 either way).  Two v_dot2_i32_i16 per 4-tap sum, the rounding bias in the
 // accumulator input, and v_ashr_pk_u8_i32 shifts, clamps and packs two values at once -- against ~14 packed/scalar float operations, a tie test and an
-// fp64 fallback per sum in the general kernel (vpp_bicubic_sep_kernel, which stays the path for every other ratio).
+// fp64 fallback per sum in the general kernel of rounds 1 / 2 (every other ratio: vpp_bicubic_cols.hip since round 3).
 //
 // Structure (separable, like the general kernel): the footprint is staged in LDS (LDS-DMA or registers); phase 1
 // evaluates H once per (staged source row, tile column) into a byte plane; phase 2 takes each thread's vertical sums

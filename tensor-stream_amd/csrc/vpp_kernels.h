@@ -91,7 +91,6 @@ struct LaunchDesc {
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
     int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
     int num_cus;            // compute units of the device (persistent grid sizing)
-    int bicubic_sep;        // 1 = separable BICUBIC kernel (H sums once per staged row, TSVPP_BICUBIC_SEP)
     int box_rx, box_ry;     // host: the AREA weight table of that axis is one row of all ones (integer ratio) -> its tap count, else 0
     int area_box_pref, area_box; // contiguous-run box kernel allowed (TSVPP_AREA_BOX) / chosen by launch_fused
     int w_dyadic;           // host: every interpolation weight of this BILINEAR / BICUBIC / AREA-up request is a multiple of 1/16
@@ -116,15 +115,16 @@ struct LaunchDesc {
     const int4 *geo_tx, *geo_ty;
     const uint4 *geo_col, *geo_row;
     int geo_pref, geo, geo_build;
-    // BICUBIC with one wave per tile and one lane per output column (vpp_bicubic_cols.hip): allowed (TSVPP_BICUBIC_COLS: 1 = non-dyadic
-    // weights, 2 = every BICUBIC request) / chosen by launch_fused (1 float, 2 integer arithmetic); bc_rows: forced tile height
+    // BICUBIC with one wave per tile and one lane per output column (vpp_bicubic_cols.hip): allowed (TSVPP_BICUBIC_COLS: 1 = what the
+    // integer kernel does not take, 2 = every BICUBIC request, 0 = never: generic gathers) / chosen by launch_fused (1 with the tie
+    // test, 2 exact coefficients); bc_rows: forced tile height
     // (TSVPP_BICUBIC_ROWS, 0 = automatic); bc_sparse: the H plane holds the four taps of each output row (vertical ratio >= 4);
-    // bc_dma_pref / bc_dma: source rows through a wave-private LDS-DMA ring (TSVPP_BICUBIC_DMA; horizontal ratios below 3.8) instead of
-    // per-lane loads; bc_ring_bytes: that ring; bc_wave_bytes: LDS bytes of one wave (ring + H plane with column stride hcs_y + result tiles)
+    // bc_dma_pref / bc_dma: source rows through a wave-private LDS-DMA ring (TSVPP_BICUBIC_DMA; horizontal ratios below 3.7) instead of
+    // per-lane loads: the 16-byte chunks (lanes) a row segment takes, 0 = direct loads; bc_ring_bytes: that ring; bc_wave_bytes: LDS bytes of one wave (ring + H plane with column stride hcs_y + result tiles)
     int bicubic_cols_pref, bicubic_cols, bc_rows, bc_sparse, bc_wave_bytes, bc_dma_pref, bc_dma, bc_ring_bytes;
-    // luma columns [dst_w] | chroma pair columns [dst_w / 2] as BcEntry records, then the rows as seven int arrays each (ws, sel, l0,
-    // l1, l2, bias, w: a wave reads four consecutive rows of one array with ONE scalar load): luma rows, chroma rows; bc_npy / bc_npc =
-    // the padded array lengths (rows rounded up to a multiple of 4, + 4)
+    // luma columns [dst_w] | chroma pair columns [dst_w / 2] as BcEntry records, then the rows in blocks of four (32 ints: ws x4 | sel x4 |
+    // l0 x4 | l1 x4 | l2 x4 | bias x4 | w x4 | pad: a wave fetches four rows' parameters with scalar loads off ONE address): luma row
+    // blocks, chroma row blocks; bc_npy / bc_npc = their numbers (rows / 4 rounded up, + 1)
     const BcEntry *bc_tab;
     int bc_npy, bc_npc;
     int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
@@ -176,7 +176,7 @@ hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable
 hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 // its per-request tables: looked up in / built into the context's cache (never while `stream` is capturing); null if unavailable
 const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool may_build);
-int bicubic_cols_rows_padded(int n); // length of one row array for n rows
+int bicubic_cols_rows_padded(int n); // row blocks for n rows
 
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
 hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);

@@ -235,330 +235,6 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_areaf_kernel(const LaunchDesc
 }
 
 // ----------------------------------------------------------------------------------------------
-// BICUBIC kernel.  Same skeleton as the 2x2-tap kernel: footprint staged by LDS-DMA, per-workgroup
-// tables -- here each output column / row gets its four tap offsets (the reference's edge rule,
-// src/Resize.cu:32-43, is baked into the offsets: no clamping at tap time) and its four Keys
-// coefficients, computed once per tile instead of once per thread and pixel.  A tap is one LDS
-// byte read at rowbase + coloffset; the 4-tap sums run in fp32 with the exact fp64 fallback of
-// cubic4_mixed near ties.
-struct BXEntry { int off[4]; float c[4]; };  // LDS byte offsets of the 4 horizontal taps, coefficients
-struct BYEntry { int base[4]; float c[4]; }; // LDS row bases of the 4 vertical taps, coefficients
-
-template <int OUT>
-__global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_kernel(const LaunchDesc d, const FrameTable t) {
-    using T = typename OutT<OUT>::type;
-    const TileId id = decode_tile(d);
-    if (!id.valid) return;
-    const int nthreads = d.tx * d.ty;
-    const int tw = d.tx * PXW, th = d.ty * PXH;
-    const Footprint f = tile_footprint<M_BICUBIC>(d, id);
-    const int chh = d.src_h >> 1;
-
-    uint8_t *lds_y = lds_raw;
-    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
-    BXEntry *xtab = (BXEntry *)(lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16);
-    BXEntry *cxtab = xtab + tw;
-    BYEntry *ytab = (BYEntry *)(cxtab + (tw >> 1));
-    BYEntry *cytab = ytab + th;
-    float *wxt = (float *)(cytab + (th >> 1)); // the weights themselves, for the exact fallback
-    float *cwxt = wxt + tw, *wyt = cwxt + (tw >> 1), *cwyt = wyt + th;
-
-    const uint8_t *ay, *auv;
-    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
-    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
-    if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
-    } else {
-        stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
-    }
-    const int ntab = tw + (tw >> 1) + th + (th >> 1);
-    for (int e = threadIdx.x; e < ntab; e += nthreads) {
-        int p, lo, hi;
-        double w;
-        float c[4];
-        if (e < tw + (tw >> 1)) { // columns: luma (step 1) then chroma pairs (step 2 bytes, U; V = U + 1)
-            const bool chroma = e >= tw;
-            const int k = chroma ? e - tw : e;
-            bicubic_axis((chroma ? (f.j_first >> 1) : f.j_first) + k, d.xr, d.src_w, p, w);
-            cubic_coeffs_f((float)w, c);
-            BXEntry en;
-            if (!chroma) {
-                bicubic_offsets(p, 1, d.src_w, lo, hi);
-                const int o = p - f.xlo;
-                en = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
-                xtab[k] = en;
-                wxt[k] = (float)w;
-            } else {
-                bicubic_offsets(2 * p, 2, d.src_w, lo, hi);
-                const int o = 2 * (p - f.cxlo);
-                en = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
-                cxtab[k] = en;
-                cwxt[k] = (float)w;
-            }
-        } else { // rows
-            const int q = e - tw - (tw >> 1);
-            const bool chroma = q >= th;
-            const int k = chroma ? q - th : q;
-            bicubic_axis((chroma ? (f.i_first >> 1) : f.i_first) + k, d.yr, d.src_h, p, w);
-            cubic_coeffs_f((float)w, c);
-            bicubic_offsets(p, 1, chroma ? chh : d.src_h, lo, hi);
-            const LdsPlane &pl = chroma ? puv : py;
-            const int r0 = p - (chroma ? f.cylo : f.ylo);
-            const int rr[4] = { r0 - lo, r0, r0 + hi, r0 + 2 * hi };
-            BYEntry en;
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                en.base[a] = rr[a] * pl.lp + ((pl.m0 + rr[a] * pl.pm) & 15);
-                en.c[a] = c[a];
-            }
-            if (!chroma) { ytab[k] = en; wyt[k] = (float)w; }
-            else { cytab[k] = en; cwyt[k] = (float)w; }
-        }
-    }
-    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
-
-    float Uf[2], Vf[2], Yf[PXH][PXW];
-    { // chroma: (U, V) evaluated as a pair -- same weights, tap addresses one byte apart
-        const BYEntry ye = cytab[ly];
-        const float wy = cwyt[ly];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const BXEntry xe = cxtab[lx * 2 + c];
-            const float wx = cwxt[lx * 2 + c];
-            f2 b[4];
-            int bu[4], bv[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                const uint8_t *row = lds_uv + ye.base[a];
-                int qu[4], qv[4];
-                f2 p[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    qu[k] = row[xe.off[k]];
-                    qv[k] = row[xe.off[k] + 1];
-                    p[k] = (f2){ (float)qu[k], (float)qv[k] };
-                }
-                b[a] = cubic4_pair(wx, wx, xe.c, xe.c, p, qu, qv);
-                bu[a] = (int)b[a].x;
-                bv[a] = (int)b[a].y;
-            }
-            const f2 v = cubic4_pair(wy, wy, ye.c, ye.c, b, bu, bv);
-            Uf[c] = v.x;
-            Vf[c] = v.y;
-        }
-    }
-    {
-        BXEntry xe[PXW];
-        float wx[PXW];
-#pragma unroll
-        for (int c = 0; c < PXW; c++) {
-            xe[c] = xtab[lx * PXW + c];
-            wx[c] = wxt[lx * PXW + c];
-        }
-#pragma unroll
-        for (int r = 0; r < PXH; r++) {
-            const BYEntry ye = ytab[ly * PXH + r];
-            const float wy = wyt[ly * PXH + r];
-#pragma unroll
-            for (int c = 0; c < PXW; c += 2) { // horizontally adjacent pixel pair
-                f2 b[4];
-                int b0[4], b1[4];
-#pragma unroll
-                for (int a = 0; a < 4; a++) {
-                    const uint8_t *row = lds_y + ye.base[a];
-                    int q0[4], q1[4];
-                    f2 p[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        q0[k] = row[xe[c].off[k]];
-                        q1[k] = row[xe[c + 1].off[k]];
-                        p[k] = (f2){ (float)q0[k], (float)q1[k] };
-                    }
-                    b[a] = cubic4_pair(wx[c], wx[c + 1], xe[c].c, xe[c + 1].c, p, q0, q1);
-                    b0[a] = (int)b[a].x;
-                    b1[a] = (int)b[a].y;
-                }
-                const f2 v = cubic4_pair(wy, wy, ye.c, ye.c, b, b0, b1);
-                Yf[r][c] = v.x;
-                Yf[r][c + 1] = v.y;
-            }
-        }
-    }
-    color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
-}
-
-// ----------------------------------------------------------------------------------------------
-// BICUBIC, separable form.  The reference's value is V(H(row y-1), H(row y), H(row y+1), H(row y+2)) where
-// H is the horizontal 4-tap sum of ONE source row, rounded and clamped to a byte (src/Resize.cu:52-62: each
-// of the five cubic interpolations ends in round + clamp), and V the same sum down the column.  H depends
-// only on (source row, output column): neighbouring output rows share most of their source rows (all but
-// ~yr of 4), so instead of 4 H sums per output value the workgroup evaluates H once per (staged source row,
-// tile column) into an LDS byte plane (phase 1) and each thread then takes its V sums from four aligned
-// dword reads per output row (phase 2).  Per 128x16 tile at ratio 1.5: 4224 pair sums instead of 7680, and
-// a third of the LDS byte reads; for up-scales the saving is larger (fewer source rows than output rows).
-struct BVEntry { int row[4]; float c[4]; }; // byte offsets (H row * tile width) of the 4 vertical taps, coefficients
-
-__device__ __forceinline__ void bicubic_vertical4(const uint8_t *h, const BVEntry &e, float w, float out[4]) {
-    f2 p01[4], p23[4];
-    int q0[4], q1[4], q2[4], q3[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const uint32_t v = *(const uint32_t *)(h + e.row[a]);
-        q0[a] = (int)(v & 255);
-        q1[a] = (int)((v >> 8) & 255);
-        q2[a] = (int)((v >> 16) & 255);
-        q3[a] = (int)(v >> 24);
-        p01[a] = (f2){ (float)q0[a], (float)q1[a] };
-        p23[a] = (f2){ (float)q2[a], (float)q3[a] };
-    }
-    const f2 a = cubic4_pair(w, w, e.c, e.c, p01, q0, q1), b = cubic4_pair(w, w, e.c, e.c, p23, q2, q3);
-    out[0] = a.x;
-    out[1] = a.y;
-    out[2] = b.x;
-    out[3] = b.y;
-}
-
-template <int OUT>
-__global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_sep_kernel(const LaunchDesc d, const FrameTable t) {
-    using T = typename OutT<OUT>::type;
-    const TileId id = decode_tile(d);
-    if (!id.valid) return;
-    const int nthreads = d.tx * d.ty;
-    const int tw = d.tx * PXW, th = d.ty * PXH * d.rpt;
-    const Footprint f = tile_footprint<M_BICUBIC>(d, id);
-    const int chh = d.src_h >> 1;
-
-    uint8_t *lds_y = lds_raw;
-    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
-    uint8_t *hy = lds_uv + d.lds_rows_uv * d.lds_cpr_uv * 16; // H planes: [staged row][tile column] bytes
-    uint8_t *huv = hy + d.lds_rows_y * tw;
-    BXEntry *xtab = (BXEntry *)(huv + d.lds_rows_uv * tw);
-    BXEntry *cxtab = xtab + tw;
-    BVEntry *ytab = (BVEntry *)(cxtab + (tw >> 1));
-    BVEntry *cytab = ytab + th;
-    float *wxt = (float *)(cytab + (th >> 1)); // the weights themselves, for the exact fallback
-    float *cwxt = wxt + tw, *wyt = cwxt + (tw >> 1), *cwyt = wyt + th;
-
-    const uint8_t *ay, *auv;
-    const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
-    const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
-    if (d.dma) {
-        stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
-        stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
-    } else {
-        stage_planes<4, 2>(d, lds_y, ay, py, ny, spy, lds_uv, auv, puv, nuv, spuv, nthreads);
-    }
-    const int ntab = tw + (tw >> 1) + th + (th >> 1);
-    for (int e = threadIdx.x; e < ntab; e += nthreads) {
-        int p, lo, hi;
-        double w;
-        float c[4];
-        if (e < tw + (tw >> 1)) { // columns: luma (step 1) then chroma pairs (step 2 bytes, U; V = U + 1)
-            const bool chroma = e >= tw;
-            const int k = chroma ? e - tw : e;
-            bicubic_axis((chroma ? (f.j_first >> 1) : f.j_first) + k, d.xr, d.src_w, p, w);
-            cubic_coeffs_f((float)w, c);
-            if (!chroma) {
-                bicubic_offsets(p, 1, d.src_w, lo, hi);
-                const int o = p - f.xlo;
-                xtab[k] = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
-                wxt[k] = (float)w;
-            } else {
-                bicubic_offsets(2 * p, 2, d.src_w, lo, hi);
-                const int o = 2 * (p - f.cxlo);
-                cxtab[k] = BXEntry{ { o - lo, o, o + hi, o + 2 * hi }, { c[0], c[1], c[2], c[3] } };
-                cwxt[k] = (float)w;
-            }
-        } else { // rows: H-plane row offsets of the four vertical taps
-            const int q = e - tw - (tw >> 1);
-            const bool chroma = q >= th;
-            const int k = chroma ? q - th : q;
-            bicubic_axis((chroma ? (f.i_first >> 1) : f.i_first) + k, d.yr, d.src_h, p, w);
-            cubic_coeffs_f((float)w, c);
-            bicubic_offsets(p, 1, chroma ? chh : d.src_h, lo, hi);
-            const int r0 = p - (chroma ? f.cylo : f.ylo);
-            const BVEntry en = { { (r0 - lo) * tw, r0 * tw, (r0 + hi) * tw, (r0 + 2 * hi) * tw }, { c[0], c[1], c[2], c[3] } };
-            if (!chroma) { ytab[k] = en; wyt[k] = (float)w; }
-            else { cytab[k] = en; cwyt[k] = (float)w; }
-        }
-    }
-    if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // phase 1: thread = luma column pair (2 cp, 2 cp + 1) and chroma column cp of the tile, striding over the staged rows
-    {
-        const int ncp = tw >> 1;
-        const int cp = threadIdx.x & (ncp - 1), rg = threadIdx.x >> (d.tx_shift + 1), nrg = nthreads >> (d.tx_shift + 1);
-        if (f.j_first + 2 * cp < d.dst_w) {
-            const BXEntry x0 = xtab[2 * cp], x1 = xtab[2 * cp + 1];
-            const float w0 = wxt[2 * cp], w1 = wxt[2 * cp + 1];
-            for (int r = rg; r < ny; r += nrg) {
-                const uint8_t *row = lds_y + r * py.lp + ((py.m0 + r * py.pm) & 15);
-                int q0[4], q1[4];
-                f2 pp[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    q0[k] = row[x0.off[k]];
-                    q1[k] = row[x1.off[k]];
-                    pp[k] = (f2){ (float)q0[k], (float)q1[k] };
-                }
-                const f2 h = cubic4_pair(w0, w1, x0.c, x1.c, pp, q0, q1);
-                *(uint16_t *)(hy + r * tw + 2 * cp) = (uint16_t)((int)h.x | ((int)h.y << 8));
-            }
-            const BXEntry cx = cxtab[cp];
-            const float cw = cwxt[cp];
-            for (int r = rg; r < nuv; r += nrg) {
-                const uint8_t *row = lds_uv + r * puv.lp + ((puv.m0 + r * puv.pm) & 15);
-                int qu[4], qv[4];
-                f2 pp[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    qu[k] = row[cx.off[k]];
-                    qv[k] = row[cx.off[k] + 1];
-                    pp[k] = (f2){ (float)qu[k], (float)qv[k] };
-                }
-                const f2 h = cubic4_pair(cw, cw, cx.c, cx.c, pp, qu, qv);
-                *(uint16_t *)(huv + r * tw + 2 * cp) = (uint16_t)((int)h.x | ((int)h.y << 8));
-            }
-        }
-    }
-    __syncthreads();
-
-    // phase 2: vertical sums of this thread's 4 columns, two output rows (one chroma row) per step
-    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = f.j_first + lx * PXW;
-    if (j0 >= d.dst_w) return;
-    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
-    for (int rp = 0; rp < d.rpt; rp++) {
-        const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
-        if (i0 >= d.dst_h) break;
-        float Uf[2], Vf[2], Yf[PXH][PXW];
-        {
-            float c4[4];
-            bicubic_vertical4(huv + lx * PXW, cytab[lyr], cwyt[lyr], c4);
-            Uf[0] = c4[0];
-            Vf[0] = c4[1];
-            Uf[1] = c4[2];
-            Vf[1] = c4[3];
-        }
-#pragma unroll
-        for (int r = 0; r < PXH; r++) bicubic_vertical4(hy + lx * PXW, ytab[lyr * PXH + r], wyt[lyr * PXH + r], Yf[r]);
-        color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
 // AREA down-scale with dyadic weights (integer ratios -> all ones; 1.5 -> {1,.5}; 2.25 -> quarters...).
 // The reference accumulates float(data) * (wx*wy) tap by tap (src/Resize.cu:160-178); when every
 // weight is k / 2^s all partial sums are exactly representable, so the result equals
@@ -1303,11 +979,6 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     } else if constexpr (MODE == M_BICUBIC) {
         if (d.bicubic_cols) return launch_bicubic_cols((OutKind)OUT, d.bicubic_cols == 2, d, t, lds_bytes, stream, info);
         if (staged && d.bicubic_int) return launch_bicubic_int((OutKind)OUT, d, t, lds_bytes, stream, info);
-        if (staged) {
-            if (d.bicubic_sep) TSVPP_LAUNCH("vpp_bicubic_sep_kernel<OUT>", (vpp_bicubic_sep_kernel<OUT>), grid, block, lds_bytes);
-            else TSVPP_LAUNCH("vpp_bicubic_kernel<OUT>", (vpp_bicubic_kernel<OUT>), grid, block, lds_bytes);
-            return info ? hipSuccess : hipGetLastError();
-        }
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
             if (vec && d.area_direct == 1 && d.area_box && !d.force_gather) // integer ratio: contiguous dword runs
@@ -1542,70 +1213,23 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     } else {
         d.point_kind = PK_NONE;
     }
-    // BICUBIC, any ratio: one wave per 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane
-    // (vpp_bicubic_cols.hip).  Tile height R (8 .. 32 output rows): the tallest one whose four waves' LDS fits the budget while the
-    // launch still has >= 4 waves per SIMD -- a taller tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter
-    // one keeps more waves in flight.
     d.bicubic_cols = 0;
     d.bc_sparse = 0;
     d.bc_dma = 0;
-    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && (d.bicubic_cols_pref == 2 || !(d.w_dyadic && d.bicubic_int_pref))) {
-        const bool sparse = d.yr >= 4.0f;
-        const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
-        // LDS-DMA ring: one global_load_lds_dword instruction fetches a row segment of <= 64 dwords (64 columns at ratio xr + window + misalignment)
-        const int nd_max = ((int)((double)d.xr * 63.0) + 2 + 6 + 1 + 6) / 4 + 1;
-        const bool dma = d.bc_dma_pref && nd_max <= 64;
-        const int ring_bytes = dma ? 16 * 4 * nd_max + 16 : 0;
-        auto col_stride = [&](int nout) { // bytes of one H-plane column: its dwords + one (phase 2 reads dword pairs), an odd number of them
-            const int rows = sparse ? 4 * nout : (int)((double)d.yr * (nout - 1)) + 6;
-            return 4 * ((((rows + 3) >> 2) + 1) | 1);
-        };
-        auto wave_bytes_of = [&](int r) { return ring_bytes + 64 * (col_stride(r) + r + r / 2); };
-        int best_r = 0;
-        for (int r = 32; r >= 8 && !best_r; r -= 8) {
-            const bool forced = d.bc_rows == r;
-            if (d.bc_rows >= 8 && d.bc_rows <= 32 && (d.bc_rows & 7) == 0 && !forced) continue;
-            const long waves = (long)((d.dst_w + 63) / 64) * ((d.dst_h + r - 1) / r) * d.n_frames;
-            if (4 * wave_bytes_of(r) > 64 * 1024) continue;
-            if (forced || r == 8 || (4 * (size_t)wave_bytes_of(r) <= kLdsBudget * 2 / 3 && waves >= 16L * d.num_cus)) best_r = r;
-        }
-        // the request's column / row tables (host-built, cached in the context): a real launch -- and the dry run of
-        // tsvpp_prepare_batch -- looks them up or builds them; while the stream is capturing and they do not exist yet the
-        // request takes the generic path below
-        if (best_r && (!info || d.geo_build)) {
-            d.bc_tab = bicubic_cols_tables(d, stream, true);
-            if (!d.bc_tab) best_r = 0;
-        }
-        if (best_r) {
-            d.bicubic_cols = exact ? 2 : 1;
-            d.bc_sparse = sparse ? 1 : 0;
-            d.bc_dma = dma ? 1 : 0;
-            d.bc_ring_bytes = ring_bytes;
-            d.bc_npy = bicubic_cols_rows_padded(d.dst_h);
-            d.bc_npc = bicubic_cols_rows_padded(d.dst_h >> 1);
-            d.hcs_y = col_stride(best_r);
-            d.hcs_uv = d.hcs_y;
-            d.bc_wave_bytes = wave_bytes_of(best_r);
-            lds_bytes = 4 * (size_t)d.bc_wave_bytes;
-            d.tx = 16; // colour phase: a wave = 16 x 4 thread tiles per 8-row slab (MergedRun: runs of 16 lanes)
-            d.ty = 4;
-            d.rpt = best_r / 8;
-            d.dma = 0;
-        }
-    }
     // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
     // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
     // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
     // 224^2 / 300^2 / 640^2, 4K -> 640x360; C3: 720p crop -> 256^2 = 14, gathers +8 %): BILINEAR gathers win from
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
-    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && ratio_area >= 30.0f);
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.bicubic_cols) {
+    // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip, below)
+    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f;
+    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
-            const bool bint = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref; // dyadic weights: integer kernel
-            const bool sep = mode == M_BICUBIC && !bint && d.bicubic_sep && sh[1] >= 2;
+            const bool bint = bicubic_staged; // dyadic weights: integer kernel
             const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx >= 2 && d.rx <= 3 && d.ry >= 2 && d.ry <= 3 && d.area2_pref;
             const bool dyadic = mode == M_AREA_DOWN && d.qx && d.qy;
             // Row pairs per thread (TSVPP_RPT; 0 = per kernel).  Taller thread tiles amortise the tile decode, staging set-up and
@@ -1614,7 +1238,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             // SHORT tiles (round 2 sweep: one row pair wins by 2..9 % on 1080p -> 720p, 4K -> 1080p and 720p -> 1080p).
             const int rpt_auto = (two_tap && f32_out) ? 1 : 2;
             const int rpt_want = d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : rpt_auto;
-            int rpt_max = ((two_tap && !d.persist) || sep || bint || area2 || dyadic) ? rpt_want : 1;
+            int rpt_max = ((two_tap && !d.persist) || bint || area2 || dyadic) ? rpt_want : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
             // (the 2x2-tap kernel wants six rounds)
@@ -1658,9 +1282,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                     c.hcs_y = 4 * (((rows_y + 3) / 4 + 2) | 1);
                     c.hcs_uv = 4 * (((rows_uv + 3) / 4 + 2) | 1);
                     need += bicubic_int_table_bytes((int)cols, (int)rows, c.rows_y, c.rows_uv, c.hcs_y, c.hcs_uv);
-                } else if (mode == M_BICUBIC) // tap-offset / coefficient tables + the raw weights (+ the H planes of the separable kernel)
-                    need += (cols + cols / 2) * (sizeof(BXEntry) + sizeof(float)) + (rows + rows / 2) * (sizeof(BYEntry) + sizeof(float)) +
-                            (sep ? (size_t)(c.rows_y + c.rows_uv) * cols : 0);
+                }
                 c.need = need;
                 c.ok = need <= kLdsBudget;
                 return c;
@@ -1688,7 +1310,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             } else {
                 // first fit: the LDS-DMA layout, then the compact register-staged one; the separable BICUBIC kernel tries
                 // a shorter tile of the SAME workgroup shape before a smaller workgroup (1080p -> 640x640: 375 k vs 288 k)
-                for (int rpt = rpt_max; rpt >= 1 && !best.ok; rpt = (sep || bint) ? rpt - 1 : 0)
+                for (int rpt = rpt_max; rpt >= 1 && !best.ok; rpt = bint ? rpt - 1 : 0)
                     for (int layout = want_dma ? 1 : 0; layout >= 0 && !best.ok; layout--) best = candidate(rpt, layout);
             }
             if (best.ok) {
@@ -1708,7 +1330,6 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                 d.lds_magic_y = 0xFFFFFFFFu / (uint32_t)best.cpr_y + 1u;
                 d.lds_magic_uv = 0xFFFFFFFFu / (uint32_t)best.cpr_uv + 1u;
                 d.dma = best.dma;
-                if (mode == M_BICUBIC) d.bicubic_sep = sep ? 1 : 0;
                 d.bicubic_int = bint ? 1 : 0;
                 d.hcs_y = best.hcs_y;
                 d.hcs_uv = best.hcs_uv;
@@ -1717,6 +1338,59 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         }
     }
     if (!staged) d.dma = 0;
+    // BICUBIC that the integer kernel above did not take (non-dyadic weights -- or TSVPP_BICUBIC_COLS=2: every request): one wave per
+    // 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane (vpp_bicubic_cols.hip).  A taller
+    // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
+    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref) {
+        const bool sparse = d.yr >= 4.0f;
+        const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
+        // LDS-DMA ring: a row segment is (64 columns at ratio xr + window + a misalignment of up to 15 bytes) rounded up to 16-byte chunks,
+        // at most 16 of them (horizontal ratios up to 3.68); bc_dma = chunks (lanes) per row; the kernel takes that path when the pitch is
+        // a multiple of 16
+        const int seg_bytes = (int)((double)d.xr * 63.0) + 2 + 7 + 15 + 1;
+        const bool dma = d.bc_dma_pref && seg_bytes <= 256;
+        const int dma_lanes = (seg_bytes + 15) / 16 < 2 ? 2 : (seg_bytes + 15) / 16;
+        const int ring_bytes = dma ? 3 * 1024 + 16 : 0;
+        auto col_stride = [&](int nout) { // bytes of one H-plane column: its dwords + one (phase 2 reads dword pairs), an odd number of them
+            const int rows = sparse ? 4 * nout : (int)((double)d.yr * (nout - 1)) + 6;
+            return 4 * ((((rows + 3) >> 2) + 1) | 1);
+        };
+        auto wave_bytes_of = [&](int r) { return ring_bytes + 64 * (col_stride(r) + r + r / 2); };
+        // Tile height, measured (profiles/r03_bicubic_cols_ab*.txt): 32 rows for up-scales (few source rows per tile: the seams cost
+        // most there; 720p -> 1080p 0.519 against 0.502 at 16), 16 rows while the launch still has 8 waves per SIMD (1080p -> 640^2 0.620
+        // against 0.609 at 8, 4K -> 1080p 0.651 against 0.624), else 8 (1080p -> 224^2 0.748 against 0.642, -> 300^2 0.404 against 0.367)
+        int best_r = 0;
+        {
+            auto waves_of = [&](int r) { return (long)((d.dst_w + 63) / 64) * ((d.dst_h + r - 1) / r) * d.n_frames; };
+            int r = d.yr <= 1.0f ? 32 : 16;
+            while (r > 8 && (waves_of(r) < 32L * d.num_cus || 4 * wave_bytes_of(r) > 40 * 1024)) r -= 8;
+            if (d.bc_rows >= 8 && d.bc_rows <= 32 && (d.bc_rows & 7) == 0) r = d.bc_rows;
+            if (4 * wave_bytes_of(r) <= 64 * 1024) best_r = r;
+        }
+        // the request's column / row tables (host-built, cached in the context): a real launch -- and the dry run of
+        // tsvpp_prepare_batch -- looks them up or builds them; while the stream is capturing and they do not exist yet the
+        // request takes the generic path below
+        if (best_r && (!info || d.geo_build)) {
+            d.bc_tab = bicubic_cols_tables(d, stream, true);
+            if (!d.bc_tab) best_r = 0;
+        }
+        if (best_r) {
+            d.bicubic_cols = exact ? 2 : 1;
+            d.bc_sparse = sparse ? 1 : 0;
+            d.bc_dma = dma ? (d.bc_dma_pref > 1 ? 16 : dma_lanes) : 0; // TSVPP_BICUBIC_DMA=2: 256-byte segments whatever the ratio (A/B)
+            d.bc_ring_bytes = ring_bytes;
+            d.bc_npy = bicubic_cols_rows_padded(d.dst_h);
+            d.bc_npc = bicubic_cols_rows_padded(d.dst_h >> 1);
+            d.hcs_y = col_stride(best_r);
+            d.hcs_uv = d.hcs_y;
+            d.bc_wave_bytes = wave_bytes_of(best_r);
+            lds_bytes = 4 * (size_t)d.bc_wave_bytes;
+            d.tx = 16; // colour phase: a wave = 16 x 4 thread tiles per 8-row slab (MergedRun: runs of 16 lanes)
+            d.ty = 4;
+            d.rpt = best_r / 8;
+            d.dma = 0;
+        }
+    }
     const size_t bc_lds = lds_bytes;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs

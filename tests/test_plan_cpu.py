@@ -75,10 +75,11 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
     ((3840, 2160), (1920, 1080), C, "vpp_bicubic_int_kernel"),          # 2: halves
     ((960, 540), (1920, 1080), C, "vpp_bicubic_int_kernel"),            # 0.5
-    ((1280, 720), (1920, 1080), C, "vpp_bicubic_sep_kernel"),           # 2/3: not dyadic -> float kernel
-    ((1080, 608), (480, 360), C, "vpp_bicubic_sep_kernel"),
+    ((1280, 720), (1920, 1080), C, "vpp_bicubic_cols_kernel<OUT,tie,dense>"),   # 2/3: not dyadic -> wave-per-tile kernel with the tie test
+    ((1080, 608), (480, 360), C, "vpp_bicubic_cols_kernel<OUT,tie,dense>"),
+    ((1920, 1080), (224, 224), C, "vpp_bicubic_cols_kernel<OUT,tie,sparse>"),    # vertical ratio >= 4: only the tapped rows are evaluated
+    ((3840, 2160), (640, 360), C, "vpp_bicubic_cols_kernel<OUT,exact,sparse>"),  # 6: dyadic, but too sparse for the staged integer kernel
     ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
-    ((1920, 1080), (224, 224), C, "vpp_fused_gather_kernel"),
 ])
 def test_kernel_families(src, dst, rt, kernel):
     p = plan(src, dst, rt)
@@ -134,7 +135,7 @@ def test_large_footprints_fall_back_to_smaller_workgroups_or_gathers():
     p = plan((7680, 4320), (2560, 1440), C)            # 8K bicubic at ratio 3 (all weights zero -> point kernel)
     assert p["kernel"].startswith("vpp_point_kernel")
     p = plan((7680, 4320), (2800, 1576), C)            # 2.74: staged bicubic must fit the 40 KiB LDS budget
-    assert p["lds"] <= 40 * 1024 and p["kernel"].startswith(("vpp_bicubic_sep_kernel", "vpp_fused_gather_kernel"))
+    assert p["lds"] <= 40 * 1024 and p["kernel"].startswith("vpp_bicubic_cols_kernel")
 
 
 def test_status_codes_match_convert():
