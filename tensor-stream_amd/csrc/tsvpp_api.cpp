@@ -209,7 +209,6 @@ struct tsvpp_ctx {
     int bilinear_win = 1;           // TSVPP_BILINEAR_WIN: window form of the float 2x2-tap thread tile
     int u8_xchg = 1;                // TSVPP_U8_XCHG: 16-byte stores for uint8 merged outputs through an in-wave LDS exchange
     int area_divtab = 1;            // TSVPP_AREA_DIVTAB: host-built divisor table for the float AREA kernels
-    int area_cols_lds = 1;          // TSVPP_AREA_COLS_LDS: stage the column-per-lane AREA kernel's footprint in LDS
     int area_cols_rows = 0;         // TSVPP_AREA_COLS_ROWS: 8 or 32 (0: by tap count)
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
@@ -217,6 +216,9 @@ struct tsvpp_ctx {
     int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
     int r32 = 1;                    // TSVPP_R32: streaming kernel for BILINEAR at exactly 3 : 2 with uint8 outputs
     int bicubic_cols = 1;           // TSVPP_BICUBIC_COLS: wave-per-tile BICUBIC kernel (1: what the integer kernel does not take, 2: every BICUBIC request, 0: off)
+    int area_stream = 1;            // TSVPP_AREA_STREAM: float-weight AREA with the source rows streamed through a wave-private LDS ring (vpp_area_stream.hip)
+    int area_stream_rows = 0;       // TSVPP_AREA_STREAM_ROWS: its tile height (4 / 8; 0 = automatic)
+    int area_stream_min_taps = 40;  // TSVPP_AREA_STREAM_MIN_TAPS: ... from this many taps (rx * ry) per value on
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
@@ -324,10 +326,12 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_STREAM")) ctx->area_stream = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_STREAM_ROWS")) ctx->area_stream_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_STREAM_MIN_TAPS")) ctx->area_stream_min_taps = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_DMA")) ctx->bicubic_dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA_COLS_LDS")) ctx->area_cols_lds = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_U8_XCHG")) ctx->u8_xchg = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_WIN")) ctx->bilinear_win = std::atoi(e);
@@ -368,11 +372,13 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.bicubic_int_pref = ctx->bicubic_int;
     d.bicubic_cols_pref = ctx->bicubic_cols;
     d.bc_rows = ctx->bicubic_rows;
+    d.area_stream_pref = ctx->area_stream;
+    d.as_rows = ctx->area_stream_rows;
+    d.as_min_taps = ctx->area_stream_min_taps;
     d.bc_dma_pref = ctx->bicubic_dma;
     d.area_box_pref = ctx->area_box;
     d.w_dyadic = pl.w_dyadic;
     d.bil_int_pref = ctx->bilinear_int;
-    d.area_cols_lds_pref = ctx->area_cols_lds;
     d.u8_xchg = ctx->u8_xchg;
     d.bil_win_pref = ctx->bilinear_win;
     d.area2_pref = ctx->area2;

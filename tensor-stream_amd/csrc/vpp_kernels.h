@@ -97,8 +97,6 @@ struct LaunchDesc {
     int bil_int_pref, bil_int; // integer 2x2-tap thread tile allowed (TSVPP_BILINEAR_INT) / chosen by launch_fused
     int bil_win_pref, bil_win;   // window form of the float 2x2-tap thread tile allowed (TSVPP_BILINEAR_WIN) / chosen by launch_fused
     int u8_xchg;                 // uint8 merged outputs: in-wave LDS exchange -> 16-byte stores (TSVPP_U8_XCHG)
-    int area_cols_rows_pref;
-    int area_cols_lds_pref, cols_lds_bytes; // LDS-staged column-per-lane AREA kernel allowed (TSVPP_AREA_COLS_LDS) / its dynamic LDS size (area_cols == 2)
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
     int area2_pref, area2;  // 2x2 float AREA kernel allowed (TSVPP_AREA2) / chosen by launch_fused
@@ -127,6 +125,10 @@ struct LaunchDesc {
     // blocks, chroma row blocks; bc_npy / bc_npc = their numbers (rows / 4 rounded up, + 1)
     const BcEntry *bc_tab;
     int bc_npy, bc_npc;
+    // float-weight AREA down-scale, one wave per tile with the source rows streamed through a wave-private LDS ring (vpp_area_stream.hip):
+    // allowed (TSVPP_AREA_STREAM) / chosen by launch_fused; as_nk: its instantiated tap count / 4 (>= nkx); as_rows: forced tile height (4 / 8,
+    // TSVPP_AREA_STREAM_ROWS).  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
+    int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_two; // as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
     int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
     GeoCache *geo_cache;
 };
@@ -178,8 +180,10 @@ hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, con
 const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool may_build);
 int bicubic_cols_rows_padded(int n); // row blocks for n rows
 
+// AREA down-scale with float weights, rows streamed through a wave-private ring (vpp_area_stream.hip).
+hipError_t launch_area_stream(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
+
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
-hipError_t launch_area_cols_lds(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // BILINEAR at exactly 3 : 2 on both axes, uint8 outputs, straight from global memory (vpp_bilinear_r32.hip).

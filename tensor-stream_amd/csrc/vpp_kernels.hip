@@ -981,6 +981,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
         if (staged && d.bicubic_int) return launch_bicubic_int((OutKind)OUT, d, t, lds_bytes, stream, info);
     } else if constexpr (MODE != M_NONE) {
         if constexpr (MODE == M_AREA_DOWN) {
+            if (d.area_stream) return launch_area_stream((OutKind)OUT, d, t, lds_bytes, stream, info);
             if (vec && d.area_direct == 1 && d.area_box && !d.force_gather) // integer ratio: contiguous dword runs
                 return launch_area_box((OutKind)OUT, d, t, stream, info);
             if (vec && d.area_direct == 1 && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
@@ -988,24 +989,16 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
-            if (vec && d.area_direct == 2 && d.area_cols == 2 && !d.force_gather) // one output column per lane, footprint staged in LDS
-                return launch_area_cols_lds((OutKind)OUT, d, t, (size_t)d.cols_lds_bytes, stream, info);
-            if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // the same, taps straight from global memory
+            if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // one output column per lane, taps straight from global memory
                 const dim3 cblock(MAX_THREADS); // 256 threads whatever the tile height
                 if (d.area_cols_rows == 32) {
                     if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
                     else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 32, OUT>", (vpp_area_cols_kernel<2, 32, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 3) TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
-                    else return hipErrorInvalidValue; // 13+ taps: 8-row tiles only (launch_fused)
+                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
                 } else {
                     if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 8, OUT>", (vpp_area_cols_kernel<1, 8, OUT>), grid, cblock, 0);
                     else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 8, OUT>", (vpp_area_cols_kernel<2, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 3) TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 4) TSVPP_LAUNCH("vpp_area_cols_kernel<4, 8, OUT>", (vpp_area_cols_kernel<4, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 5) TSVPP_LAUNCH("vpp_area_cols_kernel<5, 8, OUT>", (vpp_area_cols_kernel<5, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 6) TSVPP_LAUNCH("vpp_area_cols_kernel<6, 8, OUT>", (vpp_area_cols_kernel<6, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 7) TSVPP_LAUNCH("vpp_area_cols_kernel<7, 8, OUT>", (vpp_area_cols_kernel<7, 8, OUT>), grid, cblock, 0);
-                    else TSVPP_LAUNCH("vpp_area_cols_kernel<8, 8, OUT>", (vpp_area_cols_kernel<8, 8, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
                 }
                 return info ? hipSuccess : hipGetLastError();
             }
@@ -1148,42 +1141,46 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.area_direct = 1;
         d.area_box = 1;
     }
-    // measured (round 2, profiles/r02_area_cols_ab.txt; TSVPP_AREA_COLS=0/1/2, TSVPP_AREA_COLS_ROWS=8/32): the column-per-lane
-    // kernel wins from 5 horizontal taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 %, 4K -> 608x342 +11 %, and with 8-row tiles
-    // (four times the waves) also at 9-12 taps: 1080p -> 224^2 +11 % -- and is even at 2-4 taps
-    d.area_cols = (d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
-    d.area_cols_rows_pref = d.area_cols_rows; // TSVPP_AREA_COLS_ROWS as given (4: the LDS kernel's four-row tiles)
-    // 13-32 horizontal taps (4K -> 224 x 224, 1080p -> 128 x 72 thumbnails): only the column-per-lane kernel is instantiated that wide;
-    // without it the request takes the generic path (element-wise gathers: 4K -> 224^2 ran 2.09 ms per 64 frames, 0.05 of the roofline)
-    if (d.area_direct == 2 && d.nkx > 3 && !d.area_cols) d.area_direct = 0;
+    // Float-weight AREA: one wave per 128-column tile, the source rows streamed through a wave-private ring (vpp_area_stream.hip).  Needs the
+    // host-built divisor table, pitches that are multiples of 16 (LDS-DMA chunks), a row segment of at most 128 chunks (ratio <= ~15).
+    d.area_stream = 0;
+    size_t as_lds = 0;
+    // TSVPP_AREA_STREAM: 1 = from `as_min_taps` taps per value on (measured cross-over, profiles/r03_area_stream_ab*.txt), 2 = wherever it applies
+    if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && (d.area_stream_pref == 2 || (d.area_stream_pref == 1 && (d.rx * d.ry >= d.as_min_taps || d.nkx > 3))) && d.area_div && d.patx4 && d.paty4 && d.nkx >= 1 && d.nkx <= 8 &&
+        (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0) {
+        const int nk = d.nkx <= 4 ? d.nkx : (d.nkx <= 6 ? 6 : 8);
+        auto rowb_of = [&](int cols) {
+            const int seg_y = (int)((double)d.xr * (cols - 1)) + 1 + 4 * nk, seg_uv = 2 * ((int)((double)d.xr * (cols / 2 - 1)) + 1) + 8 * nk;
+            return ((seg_y > seg_uv ? seg_y : seg_uv) + 15 + 15) & ~15;
+        };
+        const int two = rowb_of(128) <= 2048 ? 1 : 0; // a row segment = at most two DMA instructions (128 chunks)
+        const int rowb = rowb_of(two ? 128 : 64);
+        if (rowb <= 2048) {
+            // tile height 4 (measured: 8 rows never win -- 4K -> 608x342 0.618 against 0.572, 1080p -> 160^2 0.59 against 0.47; TSVPP_AREA_STREAM_ROWS=8)
+            int r = 4;
+            if (d.as_rows == 4 || d.as_rows == 8) r = d.as_rows;
+            if (!two) r = 8;
+            d.area_stream = 1;
+            d.as_nk = nk;
+            d.as_two = two;
+            d.bc_ring_bytes = 4 * rowb + 16;
+            d.bc_wave_bytes = d.bc_ring_bytes + 128 * (r + r / 2);
+            as_lds = 4 * (size_t)d.bc_wave_bytes;
+            d.area_direct = 0;
+            d.tx = two ? 32 : 16; // colour phase: a wave = 32 x 2 thread tiles per 4-row slab, or 16 x 4 per 8-row slab (MergedRun: runs of 32 / 16 lanes)
+            d.ty = two ? 2 : 4;
+            d.rpt = two ? r / 4 : 1;
+        }
+    }
+    // Below the streaming kernel's cross-over (fewer than 40 taps per value; <= 12 horizontal taps): measured in round 2
+    // (profiles/r02_area_cols_ab.txt; TSVPP_AREA_COLS=0/1/2, TSVPP_AREA_COLS_ROWS=8/32) the column-per-lane kernel wins from 5 horizontal
+    // taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 % -- and is even at 2-4 taps
+    if (d.area_direct == 2 && d.nkx > 3) d.area_direct = 0; // (13+ taps without the streaming kernel: generic path)
+    d.area_cols = (!d.area_stream && d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
     if (d.area_cols_rows != 8 && d.area_cols_rows != 32) d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
-    if (d.nkx > 3) d.area_cols_rows = 8; // measured: 32-row tiles lose 5..50 % at 13+ taps (profiles/r02_area_wide_ab.txt)
-    d.cols_lds_bytes = 0;
     if (d.area_cols) { // fixed workgroup of 256 threads; tile = 16 x (rows / 2) thread tiles = 64 columns x 32 or 8 rows
         d.tx = 16;
         d.ty = d.area_cols_rows / 2;
-        // the tile's source footprint through LDS (vpp_area_cols.hip: 8-row tiles) while two workgroups fit a CU's 160 KiB
-        // measured (profiles/r02_area_cols_lds_ab.txt): wins from 9 horizontal taps on (1080p -> 224^2 +13 %, 4K -> 384^2 +14 %), loses
-        // at 5-8 taps, where the global kernel's windows are two or three dwords (TSVPP_AREA_COLS_LDS=2 forces it)
-        const bool want_lds = d.nkx <= 3 && (d.area_cols_lds_pref == 2 || (d.area_cols_lds_pref == 1 && d.nkx >= 3));
-        for (int th = (d.area_cols_rows_pref == 4 ? 4 : 8); want_lds && d.area_cols != 2 && th > 0; th = 0) {
-            const int span_y = span_bound(M_AREA_DOWN, 64, d.xr, d.rx), span_uv = 2 * span_bound(M_AREA_DOWN, 32, d.xr, d.rx);
-            int rows_y = span_bound(M_AREA_DOWN, th, d.yr, d.ry), rows_uv = span_bound(M_AREA_DOWN, th / 2, d.yr, d.ry);
-            const int cpr_y = (span_y + 15 + 15) / 16, cpr_uv = (span_uv + 15 + 15) / 16;
-            rows_y = ((rows_y * cpr_y + 63) / 64 * 64 + cpr_y - 1) / cpr_y; // a wave instruction fills 64 consecutive chunk slots
-            rows_uv = ((rows_uv * cpr_uv + 63) / 64 * 64 + cpr_uv - 1) / cpr_uv;
-            const size_t need = (size_t)16 * ((size_t)rows_y * cpr_y + (size_t)rows_uv * cpr_uv) + 64; // + slack for the dword over-read
-            const size_t fixed = (size_t)th * 64 * 4 + (size_t)(th / 2) * 32 * 8;                      // the kernel's static yt / uvt tiles
-            if (need + fixed > 64 * 1024) continue;
-            d.area_cols = 2;
-            d.area_cols_rows = th;
-            d.ty = th / 2;
-            d.cols_lds_bytes = (int)need;
-            d.lds_span_y = span_y; d.lds_rows_y = rows_y; d.lds_cpr_y = cpr_y;
-            d.lds_span_uv = span_uv; d.lds_rows_uv = rows_uv; d.lds_cpr_uv = cpr_uv;
-            d.lds_magic_y = 0xFFFFFFFFu / (uint32_t)cpr_y + 1u;
-            d.lds_magic_uv = 0xFFFFFFFFu / (uint32_t)cpr_uv + 1u;
-        }
     }
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
@@ -1225,7 +1222,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip, below)
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather) {
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
@@ -1427,7 +1424,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.tx_shift = slot_shift_for(d.tx);
     if (d.r32) d.bicubic_cols = 0;
     if (d.bicubic_cols) lds_bytes = bc_lds;
-    const int tile_w = d.bicubic_cols ? 256 : d.tx * (d.r32 ? 8 : PXW), tile_h = d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt; // bicubic_cols: four waves side by side
+    if (d.r32) d.area_stream = 0;
+    if (d.area_stream) lds_bytes = as_lds;
+    const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
+    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
@@ -1474,6 +1474,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     td.point_kind = PK_NONE; // the generic samplers give the point samplers' values (all weights are zero)
     td.area_direct = 0;
     td.bicubic_cols = 0;
+    td.area_stream = 0;
     td.tiles_x = 1;
     td.tiles_y = (d.dst_h + td.ty * PXH - 1) / (td.ty * PXH);
     const long rows = (long)td.tiles_y * td.n_frames;

@@ -66,11 +66,11 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((2560, 1440), (1920, 1080), A, "vpp_areaf_kernel<2,2"),            # 4/3: float weights, 2 x 2 taps
     ((1080, 608), (480, 360), A, "vpp_areaf_kernel<3,2"),               # 2.25 x 1.69
     ((1920, 1080), (800, 450), A, "vpp_area_direct_float_kernel<1"),     # 2.4: float weights from global memory
-    ((1920, 1080), (224, 224), A, "vpp_area_cols_lds_kernel<3,8,1"),     # 8.57 x 4.82: one column per lane, footprint in LDS, divisor table
-    ((3840, 2160), (224, 224), A, "vpp_area_cols_kernel<5,8"),           # 17.1 x 9.6: 18 taps (generic gathers before: 0.05 of the roofline)
-    ((3840, 2160), (128, 72), A, "vpp_area_cols_kernel<8,8"),            # 30 x 30
+    ((1920, 1080), (224, 224), A, "vpp_area_stream_kernel<3,OUT>"),     # 8.57 x 4.82 = 45 taps: rows streamed through a wave-private ring, two columns per lane
+    ((3840, 2160), (224, 224), A, "vpp_area_stream_kernel<6,OUT>"),     # 17.1 x 9.6: 18 horizontal taps (the next instantiated count: 24), 64-column tiles
+    ((3840, 2160), (128, 72), A, "vpp_area_stream_kernel<8,OUT>"),      # 30 x 30
     ((3840, 2160), (96, 54), A, "vpp_fused_gather_kernel"),              # 40 x 40: beyond 32 taps
-    ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6: one output column per lane
+    ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6 = 28 taps: below the streaming kernel's cross-over -> one output column per lane, taps from global memory
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
     ((3840, 2160), (1920, 1080), C, "vpp_bicubic_int_kernel"),          # 2: halves
