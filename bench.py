@@ -181,6 +181,37 @@ def cpu_baseline(spec, budget_s=12.0, tight_pitch=False):
             "swscale": "unavailable in image"}
 
 
+def facade_leg(dev, n_consumers=64, calls=150):
+    """The production entry (TensorStreamConverter, reference tensor_stream/tensor_stream.py:248-291) at BASELINE config C5's shape:
+    `n_consumers` consumers of ONE converter on a synthetic 4K source, served by read_many() -- one hand-off and ONE batched launch
+    per published frame, every consumer its own tensor.  Outside the timed region; wall-clock rate including the Python host side."""
+    import torch
+    import tensor_stream as ts
+    spec = WORKLOADS["c5"]
+    r = ts.TensorStreamConverter(f"synthetic://{spec[0]}x{spec[1]}?seed=3&frames=0&fps=100000&pool=3", max_consumers=n_consumers, cuda_device=dev,
+                                 framerate_mode=ts.FrameRate.FAST)
+    r.initialize()
+    r.start()
+    names = [f"consumer{i}" for i in range(n_consumers)]
+    kw = dict(width=spec[4][0], height=spec[4][1], resize_type=RESIZE[spec[5]], pixel_format=FOURCC[spec[6]], planes_pos=PLANES[spec[7]], normalization=spec[8])
+    try:
+        for _ in range(20):
+            r.read_many(names, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            r.read_many(names, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        r.stop()
+    rate = n_consumers * calls / dt
+    bpf = algorithmic_bytes(spec[0], spec[1], spec[3], spec[4], spec[8])
+    return {"entry": "TensorStreamConverter.read_many", "workload": "c5", "consumers": n_consumers, "conversions_per_s": round(rate, 1),
+            "hbm_frac": round(rate * bpf / 1e9 / HBM_PEAK_GBS, 4), "ms_per_call": round(dt * 1e3 / calls, 4),
+            "note": "one batched launch per published frame; wall clock incl. the Python host side; every consumer converts the same source frame"}
+
+
 def kernel_src_hash():
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
@@ -663,6 +694,11 @@ def run(args):
                 res["roofline"]["traffic_frac"] = round(tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as e:
             res["roofline"]["traffic_source"] = f"error: {type(e).__name__}: {e}"
+        if others is not None and world == 1:
+            try:
+                res["config"]["facade"] = facade_leg(0)
+            except Exception as e:
+                res["config"]["facade"] = {"error": f"{type(e).__name__}: {e}"}
         if others is not None:
             res["config"]["other_resize_types"] = others
         if other_wl is not None:

@@ -9,13 +9,28 @@ Same constructor, same methods, same `read()` signature and tensor shapes/dtypes
     (reference src/VideoProcessor.cpp:98-104), output written straight into a torch-owned tensor -- which also
     retires the reference's use_count()-based garbage collection of output buffers
     (src/Wrappers/WrapperPython.cpp:173-184).
+
+Batching (round 3).  The reference converts one frame per read() per consumer -- 1-3 launches and up to five cudaMalloc each.
+A single-frame launch of the fused kernel is launch-bound (~0.3 of the roofline), so the production entry
+reaches the kernel rate only if conversions with identical FrameParameters travel together:
+  * read_many(names, ...): ONE call serves many consumer names -- one hand-off under one lock, one tsvpp_convert_batch
+    launch, one output allocation; every consumer gets its own tensor (a view of the batch tensor, which it keeps alive);
+  * concurrent read() calls with identical parameters are coalesced by a leader / follower rendezvous (coalesce_window_us:
+    the first caller waits that long for others, then launches for all of them) -- same results, fewer launches; Python
+    threads stay bound by the interpreter lock (~10^4 reads/s), which read_many avoids;
+  * the producer uploads through pinned staging buffers on a copy stream (frames carry an event that consumers wait on),
+    and a synthetic source's frame pool is uploaded once.
 """
+import ctypes
 import logging
 import threading
 import time
 from enum import Enum
 
+import numpy as np
 import torch
+
+from . import _native as N
 
 from .sources import open_source
 from .vpp import FourCC, FrameParameters, Planes, ResizeType, VideoProcessor
@@ -86,19 +101,115 @@ class FrameRing:
             if self.finished:
                 raise RuntimeError("Decoding finished")
             self.status[name] = False
+            self.cv.notify_all()  # (a FAST producer waits for the hand-off)
             index = min(int(index), 0)  # reference: positive delays are forced to 0
             aligned = (self.current - 1) % self.depth + index
             if aligned < 0 or self.frames[aligned] is None:
                 return None, -1  # VREADER_REPEAT
             return self.frames[aligned], self.current
 
+    def get_many(self, names, index=0, timeout=None):
+        """get() for several consumers under ONE lock: blocks until every one of them has an unseen frame (they all see the
+        same one: the hand-off flags are set together by publish) -> ([frame per name], frame_number)."""
+        with self.cv:
+            for name in names:
+                if name not in self.status:
+                    self.status[name] = self.current > 0
+            deadline = None if timeout is None else time.monotonic() + timeout
+            while not self.finished and not all(self.status[n] for n in names):
+                if not self.cv.wait(None if deadline is None else max(0.0, deadline - time.monotonic())):
+                    if deadline is not None and time.monotonic() >= deadline:
+                        raise RuntimeError("Timeout waiting for a frame")
+            if self.finished:
+                raise RuntimeError("Decoding finished")
+            for name in names:
+                self.status[name] = False
+            self.cv.notify_all()
+            index = min(int(index), 0)
+            aligned = (self.current - 1) % self.depth + index
+            if aligned < 0 or self.frames[aligned] is None:
+                return None, -1
+            return [self.frames[aligned]] * len(names), self.current
+
     def all_consumed(self):
         with self.cv:
             return all(not v for v in self.status.values()) and len(self.status) > 0
 
+    def wait_taken(self, timeout):
+        """Producer side (FAST mode): returns once some consumer has taken the latest frame, or after `timeout` seconds -- a
+        producer without real decoding work must not spin on the interpreter lock the consumers need."""
+        with self.cv:
+            if not self.finished and (not self.status or all(self.status.values())):
+                self.cv.wait(timeout)
+
+
+_NV12_DTYPE = np.dtype([("y", np.uint64), ("uv", np.uint64), ("pitch_y", np.int32), ("pitch_uv", np.int32), ("width", np.int32), ("height", np.int32)])
+assert _NV12_DTYPE.itemsize == ctypes.sizeof(N.NV12)
+
+
+class _Group:
+    __slots__ = ("reqs", "closed", "done", "error", "out")
+
+    def __init__(self):
+        self.reqs = []      # (frame, consumer name) in arrival order
+        self.closed = False
+        self.done = threading.Event()
+        self.error = None
+        self.out = None
+
+
+class _Coalescer:
+    """Leader / follower rendezvous of concurrent conversions with identical parameters and frame geometry: the first caller
+    (leader) waits up to `window` seconds -- or until `max_batch` requests have joined -- then issues ONE batched launch for the
+    whole group and hands every caller its own slice."""
+
+    def __init__(self, convert_group, window, max_batch=N.TSVPP_MAX_BATCH):
+        self.convert_group = convert_group
+        self.window = float(window)
+        self.max_batch = int(max_batch)
+        self.lock = threading.Lock()
+        self.cv = threading.Condition(self.lock)
+        self.open = {}
+        self.launches = 0
+        self.requests = 0
+
+    def convert(self, key, frame, name, fp):
+        with self.cv:
+            grp = self.open.get(key)
+            leader = grp is None
+            if leader:
+                grp = self.open[key] = _Group()
+            slot = len(grp.reqs)
+            grp.reqs.append((frame, name))
+            self.requests += 1
+            if leader:
+                deadline = time.monotonic() + self.window
+                while len(grp.reqs) < self.max_batch:
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        break
+                    self.cv.wait(left)
+                grp.closed = True
+                del self.open[key]
+                self.launches += 1
+            elif len(grp.reqs) >= self.max_batch:
+                self.cv.notify_all()  # full: wake the leader early
+        if leader:
+            try:
+                grp.out = self.convert_group([r[0] for r in grp.reqs], fp)
+            except Exception as e:  # noqa: BLE001
+                grp.error = e
+            grp.done.set()
+        else:
+            grp.done.wait()
+        if grp.error is not None:
+            raise grp.error
+        return grp.out[slot]
+
 
 class TensorStreamConverter:
-    def __init__(self, stream_url, max_consumers=5, cuda_device=None, buffer_size=5, framerate_mode=FrameRate.NATIVE, timeout=None):
+    def __init__(self, stream_url, max_consumers=5, cuda_device=None, buffer_size=5, framerate_mode=FrameRate.NATIVE, timeout=None,
+                 coalesce_window_us=0):
         self.log = logging.getLogger(__name__)
         self.thread = None
         self.fps = None
@@ -116,6 +227,10 @@ class TensorStreamConverter:
         self._stop = threading.Event()
         self._logs = (LogsLevel.NONE, LogsType.CONSOLE)
         self._markers = False
+        self.coalesce_window_us = float(coalesce_window_us)  # > 0: concurrent read() calls with identical parameters share a launch
+        self._coalescer = None
+        self._copy_stream = None
+        self._desc_cache = {}
 
     # ---- lifecycle -------------------------------------------------------------------------------
     def initialize(self, repeat_number=1):
@@ -125,8 +240,10 @@ class TensorStreamConverter:
                 self._source = open_source(self.stream_url)
                 self._vpp = VideoProcessor(device=self.cuda_device, max_consumers=self.max_consumers)
                 if self._markers:
-                    self._vpp.enable_markers(True)
+                    self._enable_markers()
                 self._ring = FrameRing(self.buffer_size)
+                self._coalescer = _Coalescer(self._convert_group, self.coalesce_window_us * 1e-6) if self.coalesce_window_us > 0 else None
+                self._desc_cache = {}
                 self._stop.clear()
                 self.fps = self._source.fps_num / self._source.fps_den
                 self.frame_size = (self._source.width, self._source.height)
@@ -141,11 +258,18 @@ class TensorStreamConverter:
 
     def enable_nvtx(self):
         """Reference: NVTX ranges around the pipeline stages (tensor_stream/tensor_stream.py enable_nvtx,
-        include/Common.h:72-105).  Here: roctx ranges around every conversion, visible to rocprofv3 --marker-trace.
+        include/Common.h:72-105), a harmless toggle.  Here: roctx ranges around every conversion, visible to
+        rocprofv3 --marker-trace; on a machine without a roctx library the toggle stays harmless (logged, not raised).
         May be called before or after initialize(), like the reference's."""
         self._markers = True
         if self._vpp is not None:
+            self._enable_markers()
+
+    def _enable_markers(self):
+        try:
             self._vpp.enable_markers(True)
+        except RuntimeError as e:  # no roctx library: VideoProcessor.enable_markers raises, the facade's toggle does not
+            self.log.warning("enable_nvtx: %s", e)
 
     def set_timeout(self, timeout):
         self._timeout = None if timeout is None else float(timeout)
@@ -160,21 +284,56 @@ class TensorStreamConverter:
         period = src.fps_den / src.fps_num if src.fps_num else 0.0
         nxt = time.monotonic()
         dev = torch.device("cuda", self.cuda_device)
+        # Uploads: pinned staging buffers, asynchronous copies on a copy stream, an event per frame that the consumers' streams
+        # wait on (never the host).  Device frames are fresh allocations of the copy stream (consumers record their own streams on
+        # them, so the allocator does not recycle a frame under a running conversion).  A source that cycles through a fixed pool
+        # of arrays (synthetic) is uploaded once.
+        copy_stream = torch.cuda.Stream(device=dev)
+        resident = {}                       # id(host array pair) -> frame, for sources with a fixed pool
+        nslots = 3                          # pinned staging pairs
+        staging, staged_ev, k = [None] * nslots, [None] * nslots, 0
+        fixed_pool = getattr(src, "pool", None) is not None
         while not self._stop.is_set():
             f = src.next_frame()
             if f is None:
                 break
-            y = torch.from_numpy(f[0]).to(dev, non_blocking=False)
-            uv = torch.from_numpy(f[1]).to(dev, non_blocking=False)
-            ring.publish((y, uv))
+            key = (id(f[0]), id(f[1]))
+            item = resident.get(key) if fixed_pool else None
+            if item is None:
+                if staging[k] is None:
+                    staging[k] = (torch.empty(f[0].shape, dtype=torch.uint8).pin_memory(), torch.empty(f[1].shape, dtype=torch.uint8).pin_memory())
+                elif staged_ev[k] is not None:
+                    staged_ev[k].synchronize()  # the copy that last read this staging pair
+                hy, huv = staging[k]
+                hy.numpy()[...] = f[0]
+                huv.numpy()[...] = f[1]
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(copy_stream):
+                    dy = torch.empty(f[0].shape, dtype=torch.uint8, device=dev)
+                    duv = torch.empty(f[1].shape, dtype=torch.uint8, device=dev)
+                    dy.copy_(hy, non_blocking=True)
+                    duv.copy_(huv, non_blocking=True)
+                    ev.record(copy_stream)
+                staged_ev[k] = ev
+                k = (k + 1) % nslots
+                if fixed_pool:
+                    ev.synchronize()
+                    resident[key] = item = (dy, duv, None)
+                else:
+                    item = (dy, duv, ev)
+            ring.publish(item)
             if self.framerate_mode == FrameRate.BLOCKING:
                 while not self._stop.is_set() and not ring.all_consumed():  # frame by frame, nobody skips
-                    time.sleep(0.0005)
+                    time.sleep(0.0002)
             elif self.framerate_mode != FrameRate.FAST and period > 0:
                 nxt += period
                 delay = nxt - time.monotonic()
                 if delay > 0:
                     self._stop.wait(delay)
+            elif self.framerate_mode == FrameRate.FAST:
+                # no pacing -- but a producer without real decoding work must neither spin on the interpreter lock the consumers need
+                # nor ping-pong with them frame by frame (two thread wake-ups per frame): ~10^4 frames/s, ahead of any consumer
+                time.sleep(5e-5)
         ring.finish()
 
     def start(self):
@@ -208,13 +367,81 @@ class TensorStreamConverter:
         frame, index = None, -1
         while frame is None:  # VREADER_REPEAT loop of TensorStream::getFrame (src/Wrappers/WrapperPython.cpp:300-306)
             frame, index = self._ring.get(name, delay, self._timeout)
-        y, uv = frame
-        tensor = self._vpp.Convert(y, uv, frame_parameters, consumer=name)
+        y, uv, ev = frame
+        if self._coalescer is not None:
+            self._vpp.consumer_stream(name)  # claims the consumer's pool slot (reference: a 6th name on a pool of 5 is an error)
+            p = frame_parameters.parameters
+            key = (bytes(p), tuple(y.shape), y.stride(0), uv.stride(0))
+            tensor = self._coalescer.convert(key, frame, name, frame_parameters)
+        else:
+            if ev is not None:
+                torch.cuda.current_stream(self.cuda_device).wait_event(ev)  # (the consumer's pooled stream waits for the current one)
+            tensor = self._vpp.Convert(y, uv, frame_parameters, consumer=name)
+            if ev is not None:
+                # The frame's memory must outlive the conversion enqueued on the consumer's pooled stream.  Convert() has made torch's
+                # current stream wait for that stream, so recording the CURRENT stream (torch-owned, never destroyed -- the pooled one
+                # dies with the context, before the allocator may want to query it) on the frame orders its reuse after the conversion.
+                cur = torch.cuda.current_stream(self.cuda_device)
+                y.record_stream(cur)
+                uv.record_stream(cur)
         return (tensor, index) if return_index else tensor
+
+    def _convert_group(self, frames, fp):
+        """ONE batched launch for `frames` (list of (y, uv, event)) with parameters `fp` on torch's current stream -> batch tensor
+        (n, ...): slice i belongs to request i and keeps the batch alive."""
+        vpp, n = self._vpp, len(frames)
+        cur = torch.cuda.current_stream(self.cuda_device)
+        waited = set()
+        for f in frames:
+            if f[2] is not None and id(f[2]) not in waited:
+                cur.wait_event(f[2])
+                waited.add(id(f[2]))
+                f[0].record_stream(cur)  # the frame's memory must outlive the conversion enqueued below
+                f[1].record_stream(cur)
+        y0, uv0 = frames[0][0], frames[0][1]
+        w, h = y0.shape[1], y0.shape[0]
+        p = fp.parameters
+        out = vpp._alloc(p, w, h, n)
+        # descriptor arrays without a Python loop over struct fields: numpy records with the layout of tsvpp_nv12
+        rec = np.empty(n, dtype=_NV12_DTYPE)
+        rec["y"] = [f[0].data_ptr() for f in frames]
+        rec["uv"] = [f[1].data_ptr() for f in frames]
+        rec["pitch_y"], rec["pitch_uv"], rec["width"], rec["height"] = y0.stride(0), uv0.stride(0), w, h
+        outs = np.arange(n, dtype=np.uint64) * np.uint64(out.stride(0) * out.element_size()) + np.uint64(out.data_ptr())
+        N.check(vpp._lib.tsvpp_convert_batch(vpp._ctx, n, rec.ctypes.data_as(ctypes.POINTER(N.NV12)), ctypes.byref(p),
+                                             outs.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), cur.cuda_stream))
+        return out
+
+    def read_many(self, names, width=0, height=0, resize_type=ResizeType.NEAREST, crop_coords=(0, 0, 0, 0), pixel_format=FourCC.RGB24,
+                  planes_pos=Planes.MERGED, normalization=None, delay=0, return_index=False):
+        """read() for several consumer names at once: every consumer takes its next frame (the hand-off semantics of read(), under
+        one lock), ONE batched launch converts them all, and the result is a list of tensors -- one per name, each a view of one
+        batch tensor that it keeps alive.  This is how the facade reaches the kernel's rate: a launch per frame is launch-bound."""
+        if self._ring is None or self._vpp is None:
+            raise RuntimeError("-3")
+        names = list(names)
+        if len(names) > self.max_consumers:
+            raise RuntimeError("-3")  # more consumers than the pool holds (reference src/VideoProcessor.cpp:100-103)
+        fp = FrameParameters(width=width, height=height, crop_coords=crop_coords, resize_type=resize_type, pixel_format=pixel_format,
+                             planes_pos=planes_pos, normalization=normalization)
+        frames, index = None, -1
+        while frames is None:
+            frames, index = self._ring.get_many(names, delay, self._timeout)
+        out = self._convert_group(frames, fp)
+        tensors = [out[i] for i in range(len(names))]
+        return (tensors, index) if return_index else tensors
 
     def dump(self, tensor, name="default", width=0, height=0, crop_coords=(0, 0, 0, 0), resize_type=ResizeType.NEAREST,
              pixel_format=FourCC.RGB24, planes_pos=Planes.MERGED, normalization=None):
-        """Appends the tensor's raw elements to <name>.yuv (reference src/Wrappers/WrapperPython.cpp:421-456)."""
+        """Appends the tensor's raw elements to <name>.yuv (reference src/Wrappers/WrapperPython.cpp:421-456: the tensor is
+        checked against the size / format arguments, a mismatch is an error)."""
+        if width or height:
+            fp = FrameParameters(width=width, height=height, crop_coords=crop_coords, resize_type=resize_type, pixel_format=pixel_format,
+                                 planes_pos=planes_pos, normalization=normalization)
+            from .vpp import output_shape
+            want = output_shape(fp.parameters, int(width), int(height))
+            if tuple(tensor.shape) != tuple(want):
+                raise RuntimeError(f"-3: tensor shape {tuple(tensor.shape)} does not match the dump parameters {tuple(want)}")
         torch.cuda.synchronize(tensor.device)  # conversions run asynchronously on the consumer's stream
         with open(name + ".yuv", "ab+") as f:
             f.write(tensor.contiguous().cpu().numpy().tobytes())

@@ -91,3 +91,83 @@ def test_facade_constructor_and_errors_without_gpu():
     bad = ts.TensorStreamConverter("wrong.h264")
     with pytest.raises(RuntimeError, match="Can't initialize TensorStream"):
         bad.initialize(repeat_number=5)
+
+
+def test_ring_get_many_hands_every_consumer_the_same_new_frame_once():
+    from tensor_stream.tensor_stream import FrameRing
+    ring = FrameRing(3)
+    names = [f"c{i}" for i in range(8)]
+    got = []
+
+    def consumer():
+        try:
+            while True:
+                frames, idx = ring.get_many(names, 0, timeout=5)
+                got.append((idx, frames))
+        except RuntimeError as e:
+            got.append(str(e))
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    for k in range(4):
+        ring.publish(("frame", k))
+        while not ring.all_consumed():
+            time.sleep(0.001)
+    ring.finish()
+    t.join(timeout=5)
+    assert got[-1] == "Decoding finished"
+    assert [g[0] for g in got[:-1]] == [1, 2, 3, 4]
+    for idx, frames in got[:-1]:
+        assert len(frames) == 8 and all(f == ("frame", idx - 1) for f in frames)
+    # a single-name get() after get_many() of the same frame sees nothing new: one hand-off per consumer and frame
+    ring2 = FrameRing(2)
+    ring2.publish("a")
+    ring2.get_many(["x", "y"])
+    with pytest.raises(RuntimeError, match="Timeout"):
+        ring2.get("x", 0, timeout=0.05)
+
+
+def test_coalescer_groups_concurrent_requests_and_returns_each_its_slice():
+    from tensor_stream.tensor_stream import _Coalescer
+    calls = []
+
+    def convert_group(frames, fp):
+        calls.append(len(frames))
+        time.sleep(0.002)
+        return [("out", f, fp) for f in frames]
+
+    co = _Coalescer(convert_group, window=0.05, max_batch=16)
+    res, errs = {}, []
+
+    def work(i):
+        try:
+            res[i] = co.convert(("k", i % 2), ("frame", i), f"c{i}", "fp%d" % (i % 2))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(32)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=10)
+    assert not errs and len(res) == 32
+    for i in range(32):
+        assert res[i] == ("out", ("frame", i), "fp%d" % (i % 2))   # every caller got ITS frame converted with ITS parameters
+    assert sum(calls) == 32 and len(calls) <= 6 and max(calls) <= 16  # two keys x 16 = full groups wake the leader early
+    assert co.requests == 32 and co.launches == len(calls)
+    # an error in the batched conversion reaches every member of the group
+    co2 = _Coalescer(lambda frames, fp: (_ for _ in ()).throw(RuntimeError("boom")), window=0.02)
+    out = []
+
+    def bad():
+        try:
+            co2.convert("k", 1, "c", None)
+        except RuntimeError as e:
+            out.append(str(e))
+
+    th = [threading.Thread(target=bad) for _ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=5)
+    assert out == ["boom"] * 4
