@@ -1,9 +1,10 @@
 // VideoProcessor.h -- the reference's VPP class, re-hosted on the MI355X C ABI (include/tsvpp.h).
 //
 // Same public surface as reference include/VideoProcessor.h:20-149 (enum values, option structs,
-// class methods and argument meaning), so `TensorStream::getFrame` (reference
-// src/Wrappers/WrapperPython.cpp:312, src/Wrappers/WrapperC.cpp:291) and the reference's VPP tests
-// (tests/src/VPPTests.cpp) compile against it unchanged; cudaStream_t becomes hipStream_t.
+// class methods and argument meaning) for `TensorStream::getFrame` (reference src/Wrappers/WrapperPython.cpp:312,
+// src/Wrappers/WrapperC.cpp:291); cudaStream_t becomes hipStream_t.  No gtest and no FFmpeg exist in this image, so the reference's
+// VPP tests themselves are not compiled: vpp_goldens.cpp replays their harness (tests/src/VPPTests.cpp:101-132 -- Init, Convert,
+// CRC of opaque, DumpFrame, CRC of the file) with all 38 CRC literals of the reference (tests/test_cpp_goldens_gpu.py).
 // Everything device-side lives behind tsvpp_*; this file is a thin adapter.
 //
 // AVFrame: when FFmpeg's <libavutil/frame.h> is on the include path it is used; otherwise (this
