@@ -212,18 +212,35 @@ def facade_leg(dev, n_consumers=64, calls=150):
             "note": "one batched launch per published frame; wall clock incl. the Python host side; every consumer converts the same source frame"}
 
 
-def kernel_src_hash():
+_SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
+_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
+                 ("vpp_bicubic_cols", "vpp_bicubic_cols.hip"), ("vpp_area_box", "vpp_area_box.hip"), ("vpp_area_stream", "vpp_area_stream.hip"),
+                 ("fmt_", "vpp_formats.hip")]
+
+
+def kernel_source_files(kernel=None):
+    """The sources a PMC traffic entry depends on: the dispatched kernel's translation unit + the shared device headers (kernel =
+    the name bench.py prints in roofline.kernel); without a kernel name: every kernel source."""
+    if not kernel:
+        return list(KERNEL_SOURCES)
+    k = kernel.split("::")[-1]
+    unit = next((f for prefix, f in _KERNEL_FILES if k.startswith(prefix)), "vpp_kernels.hip")
+    return ["tensor-stream_amd/csrc/" + unit] + _SHARED_SOURCES
+
+
+def kernel_src_hash(kernel=None):
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
+    for rel in kernel_source_files(kernel):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def lookup_traffic(workload, frames_per_launch, path=None):
+def lookup_traffic(workload, frames_per_launch, path=None, kernel=None):
     """HBM bytes per launch from the committed PMC passes (tools/profile.sh -> tools/traffic_json.py).  The counters
     need their own rocprofv3 runs, so this is the last PROFILED value for this workload -- returned only when the entry
-    was taken with the kernel sources as they are now (`kernel_src_sha`); a stale entry yields (None, reason)."""
+    was taken on the kernel that is dispatched now, with that kernel's sources (its translation unit + the shared device
+    headers) as they are now (`kernel_src_sha`); a stale entry yields (None, reason)."""
     path = path or os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         tr = json.load(open(path)).get(workload)
@@ -233,9 +250,12 @@ def lookup_traffic(workload, frames_per_launch, path=None):
         return None, "no PMC entry for this workload"
     if tr.get("frames_per_launch") != frames_per_launch:
         return None, "PMC entry is for another launch size"
-    if tr.get("kernel_src_sha") != kernel_src_hash():
+    if kernel and tr.get("kernel") and tr["kernel"] != kernel:
+        return None, f"stale PMC entry ({tr.get('round')}): it profiled {tr['kernel']}, the launch now dispatches {kernel}"
+    want = kernel_src_hash(tr.get("kernel") if tr.get("kernel") else None)
+    if tr.get("kernel_src_sha") != want:
         return None, f"stale PMC entry ({tr.get('round')}): kernel sources changed since it was profiled"
-    return tr["hbm_bytes_per_launch"], f"profiles/traffic_latest.json ({tr['round']}, kernel_src_sha {tr['kernel_src_sha']}): 2*FETCH_SIZE+WRITE_SIZE, KiB"
+    return tr["hbm_bytes_per_launch"], f"profiles/traffic_latest.json ({tr['round']}, {tr.get('kernel', 'all kernels')}, kernel_src_sha {tr['kernel_src_sha']}): 2*FETCH_SIZE+WRITE_SIZE, KiB"
 
 
 def parse_args(argv=None):
@@ -687,7 +707,7 @@ def run(args):
         except Exception as e:
             res["roofline"]["touched_bytes"] = {"error": f"{type(e).__name__}: {e}"}
         try:
-            tr, why = lookup_traffic(name if not args.resize else (args.resize.lower() if name == "headline" else ""), fpl)
+            tr, why = lookup_traffic(name if not args.resize else (args.resize.lower() if name == "headline" else ""), fpl, kernel=res["roofline"]["kernel"])
             res["roofline"]["traffic"] = tr
             res["roofline"]["traffic_source"] = why
             if tr:  # the fraction of the peak on the bytes the launch actually moved (C3 / C4: below the ROI formula)

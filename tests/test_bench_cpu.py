@@ -137,6 +137,14 @@ def test_stale_traffic_entries_are_dropped(tmp_path):
     for w in ("c2", "c5", "c3"):
         tr, why = bench.lookup_traffic(w, 64.0, str(p))
         assert tr is None and why
+    # per-kernel stamps: valid while THAT kernel's translation unit and the shared headers are unchanged, and only for that kernel
+    k = "tsvpp::vpp_bilinear_kernel<bilinear,OUT>"
+    assert bench.kernel_source_files(k)[0].endswith("vpp_bilinear.hip") and bench.kernel_source_files("tsvpp::vpp_color_kernel<OUT>")[0].endswith("vpp_kernels.hip")
+    assert bench.kernel_source_files("tsvpp::vpp_bilinear_r32_kernel<OUT,1,4>")[0].endswith("vpp_bilinear_r32.hip")
+    p.write_text(json.dumps({"headline": dict(good, kernel=k, kernel_src_sha=bench.kernel_src_hash(k))}))
+    assert bench.lookup_traffic("headline", 64.0, str(p), kernel=k)[0] == 123
+    tr, why = bench.lookup_traffic("headline", 64.0, str(p), kernel="tsvpp::vpp_bicubic_int_kernel<OUT>")
+    assert tr is None and "dispatches" in why
 
 
 def test_torchrun_world1_takes_the_collective_path_on_gloo():

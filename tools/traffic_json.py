@@ -23,7 +23,8 @@ w, nw = mean(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WR
 bench = json.loads([l for l in open(os.path.join(src, "kt.log")) if l.startswith('{"metric"')][-1])
 out_path = "profiles/traffic_latest.json"
 db = json.load(open(out_path)) if os.path.exists(out_path) else {}
-db[tag] = {"round": rnd, "kernel_src_sha": kernel_src_hash(), "fetch_size_kib": f, "write_size_kib": w, "dispatches": min(nf, nw),
+kernel = bench["roofline"].get("kernel")  # per-kernel stamp: a change to another kernel's translation unit does not invalidate this entry
+db[tag] = {"round": rnd, "kernel": kernel, "kernel_src_sha": kernel_src_hash(kernel), "fetch_size_kib": f, "write_size_kib": w, "dispatches": min(nf, nw),
            "hbm_bytes_per_launch": int((2 * f + w) * 1024), "read_bytes": int(2 * f * 1024), "write_bytes": int(w * 1024),
            "frames_per_launch": bench["config"]["frames_per_launch"], "algorithmic_bytes_per_launch":
            int(bench["roofline"]["bytes_per_frame"] * bench["config"]["frames_per_launch"]),
