@@ -195,30 +195,28 @@ struct tsvpp_ctx {
     std::map<uint64_t, float *> area_div; // divisor tables, keyed by both scales' bit patterns (null: too large, not built)
     int force_gather = 0;               // TSVPP_FORCE_GATHER=1: always use the global-gather kernel (A/B, tests)
     int nt_stores = -1, tile_order = 0, shape_tx = 0, shape_ty = 0; // TSVPP_NT, TSVPP_TILE_ORDER, TSVPP_SHAPE=tx,ty
-    int ablate = 0;
-    int persist = 0, num_cus = 256; // TSVPP_PERSIST
+    int num_cus = 256;
     // dyadic AREA reads straight from global memory from this ratio on (both axes); below it the LDS kernel wins
     // (measured after its VGPR fix: 2x 501 k vs 368 k fps, 3x 743 k vs 621 k, 4x 162 k vs 251 k)
     float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
-    float area_direct_fmin = 2.0f;  // TSVPP_AREA_DIRECT_FMIN: the same for non-dyadic weights
+    float area_direct_fmin = 2.0f;  // the same for non-dyadic weights (a constant since round 3)
     int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
     int bilinear_int = 1;           // TSVPP_BILINEAR_INT: integer thread tile of the 2x2-tap kernel for dyadic weights
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
-    int area2 = 1;                  // TSVPP_AREA2
-    int lds_kb = 40;                // TSVPP_LDS_KB
-    int bilinear_win = 1;           // TSVPP_BILINEAR_WIN: window form of the float 2x2-tap thread tile
-    int u8_xchg = 1;                // TSVPP_U8_XCHG: 16-byte stores for uint8 merged outputs through an in-wave LDS exchange
+    int area2 = 1;                  // float-weight AREA at 2 x 2 .. 3 x 3 taps on its own LDS kernel
+    int lds_kb = 40;                // LDS bytes a staged workgroup may use (four workgroups per CU)
+    int bilinear_win = 1;           // window form of the float 2x2-tap thread tile where it measured faster (ratios 1 .. 1.45)
+    int u8_xchg = 1;                // 16-byte stores for uint8 merged outputs through an in-wave LDS exchange
     int area_divtab = 1;            // TSVPP_AREA_DIVTAB: host-built divisor table for the float AREA kernels
-    int area_cols_rows = 0;         // TSVPP_AREA_COLS_ROWS: 8 or 32 (0: by tap count)
+    int area_cols_rows = 0;         // tile height of the column-per-lane AREA kernel: by tap count
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
-    int dma_pow2 = 0;               // TSVPP_DMA_POW2=1: the round-1 LDS-DMA layout (power-of-two row pitch), A/B only
     int r32 = 1;                    // TSVPP_R32: streaming kernel for BILINEAR at exactly 3 : 2 with uint8 outputs
     int bicubic_cols = 1;           // TSVPP_BICUBIC_COLS: wave-per-tile BICUBIC kernel (1: what the integer kernel does not take, 2: every BICUBIC request, 0: off)
     int area_stream = 1;            // TSVPP_AREA_STREAM: float-weight AREA with the source rows streamed through a wave-private LDS ring (vpp_area_stream.hip)
-    int area_stream_rows = 0;       // TSVPP_AREA_STREAM_ROWS: its tile height (4 / 8; 0 = automatic)
-    int area_stream_min_taps = 40;  // TSVPP_AREA_STREAM_MIN_TAPS: ... from this many taps (rx * ry) per value on
+    int area_stream_rows = 0;       // its tile height: automatic (4)
+    int area_stream_min_taps = 40;  // ... from this many taps (rx * ry) per value on (measured cross-over)
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
@@ -314,31 +312,20 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
 void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *fg = std::getenv("TSVPP_FORCE_GATHER")) ctx->force_gather = (fg[0] == '1');
     if (const char *e = std::getenv("TSVPP_NT")) ctx->nt_stores = std::atoi(e); // 0 plain, 1 nt, 2 sc1; default -1 = per kernel
-    if (const char *e = std::getenv("TSVPP_ABLATE")) ctx->ablate = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_PERSIST")) ctx->persist = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_DMA")) ctx->dma = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_DMA_POW2")) ctx->dma_pow2 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_GEO")) ctx->geo_pref = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_R32")) ctx->r32 = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_RPT")) ctx->rpt = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
-    if (const char *e = std::getenv("TSVPP_AREA_DIRECT_FMIN")) ctx->area_direct_fmin = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_STREAM")) ctx->area_stream = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA_STREAM_ROWS")) ctx->area_stream_rows = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA_STREAM_MIN_TAPS")) ctx->area_stream_min_taps = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_DMA")) ctx->bicubic_dma = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_BOX")) ctx->area_box = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_U8_XCHG")) ctx->u8_xchg = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_BILINEAR_WIN")) ctx->bilinear_win = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA2")) ctx->area2 = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
-    if (const char *e = std::getenv("TSVPP_AREA_COLS_ROWS")) ctx->area_cols_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
 }
@@ -362,10 +349,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.tile_order = ctx->tile_order;
     d.shape_tx = ctx->shape_tx;
     d.shape_ty = ctx->shape_ty;
-    d.ablate = ctx->ablate;
-    d.persist = ctx->persist;
     d.dma = ctx->dma;
-    d.dma_pow2 = ctx->dma_pow2;
     d.rpt_pref = ctx->rpt;
     d.area_direct_min = ctx->area_direct_min;
     d.area_direct_fmin = ctx->area_direct_fmin;

@@ -63,25 +63,6 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
 
     // chroma: (U, V) of one block blended as a float pair
     float Uf[2], Vf[2], Yf[PXH][PXW];
-#ifdef TSVPP_ABLATION
-    if (d.ablate & 4) { // profiling: staging + stores only
-        for (int c = 0; c < 2; c++) Uf[c] = Vf[c] = (float)lds_uv[cye.top + cxe[c].off];
-        for (int r = 0; r < PXH; r++)
-            for (int c = 0; c < PXW; c++) Yf[r][c] = (float)lds_y[ye[r].top + xe[c].off];
-        if (d.ablate & 1) { // loads only
-            float acc = Uf[0] + Vf[1];
-            for (int r = 0; r < PXH; r++)
-                for (int c = 0; c < PXW; c++) acc += Yf[r][c];
-            if (acc == -1.0f) ((float *)out)[0] = acc;
-            return;
-        }
-        const size_t plane = (size_t)d.dst_w * d.dst_h;
-        float *o = (float *)out;
-        for (int r = 0; r < PXH; r++)
-            for (int p = 0; p < 3; p++) st4(o + p * plane + (size_t)(i0 + r) * d.dst_w + j0, Yf[r][0], Yf[r][1], Yf[r][2], Yf[r][3], d.nt_stores);
-        return;
-    }
-#endif
     {
         const f2 wy = { cye.w, cye.w }, omy = (f2){ 1.0f, 1.0f } - wy;
 #pragma unroll
@@ -113,15 +94,6 @@ __device__ __forceinline__ void bilinear_thread_tile(const LaunchDesc &d, const 
             Yf[r][2 * p + 1] = __builtin_truncf(sum.y);
         }
     }
-#ifdef TSVPP_ABLATION
-    if (d.ablate & 1) { // profiling: keep the arithmetic alive without the HBM writes
-        float acc = Uf[0] + Vf[0] + Uf[1] + Vf[1];
-        for (int r = 0; r < PXH; r++)
-            for (int c = 0; c < PXW; c++) acc += Yf[r][c];
-        if (acc == -1.0f) ((float *)out)[0] = acc;
-        return;
-    }
-#endif
     color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
@@ -347,9 +319,6 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
     const LdsPlane py = describe_plane(lds_y, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
     const LdsPlane puv = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
     const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-#ifdef TSVPP_ABLATION
-    if (!(d.ablate & 2))
-#endif
     if (d.dma) {
         stage_plane_dma(lds_y, ay, py, d.pitch_y, ny, min(f.xhi - f.xlo + 1, d.lds_span_y), d.lds_magic_y, nthreads);
         stage_plane_dma(lds_uv, auv, puv, d.pitch_uv, nuv, min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv), d.lds_magic_uv, nthreads);
@@ -540,129 +509,6 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_geo_kernel(const Lau
 }
 
 // ----------------------------------------------------------------------------------------------
-// Persistent variant of the 2x2-tap kernel (opt-in, TSVPP_PERSIST=k workgroups per CU).  A fixed
-// grid of resident workgroups walks the tile list (tile = block + i * grid: neighbouring
-// workgroups still write neighbouring tiles).  LDS holds TWO tile sets; while set `cur` is blended,
-// colour-converted and stored, the NEXT tile's chunks stream into the other set by LDS-DMA -- no
-// registers held across the compute phase -- and its coordinate tables are built.  One barrier per
-// tile (two on right-edge tiles).
-struct TileCtx {
-    TileId id;
-    Footprint f;
-    LdsPlane py, puv;
-    const uint8_t *ay, *auv;
-    int ny, nuv, span_y, span_uv;
-};
-template <int MODE>
-__device__ __forceinline__ void tile_ctx(const LaunchDesc &d, const FrameTable &t, int tile, uint8_t *lds_y, uint8_t *lds_uv, TileCtx &c) {
-    const int tiles = d.tiles_x * d.tiles_y;
-    c.id.frame = tile / tiles;
-    const int rem = tile - c.id.frame * tiles;
-    c.id.ty = rem / d.tiles_x;
-    c.id.tx = rem - c.id.ty * d.tiles_x;
-    c.id.valid = true;
-    c.f = tile_footprint<MODE>(d, c.id);
-    c.py = describe_plane(lds_y, t.y[c.id.frame], d.pitch_y, c.f.ylo, c.f.xlo, d.lds_cpr_y, c.ay);
-    c.puv = describe_plane(lds_uv, t.uv[c.id.frame], d.pitch_uv, c.f.cylo, 2 * c.f.cxlo, d.lds_cpr_uv, c.auv);
-    c.ny = min(c.f.yhi - c.f.ylo + 1, d.lds_rows_y);
-    c.nuv = d.luma_only ? 0 : min(c.f.cyhi - c.f.cylo + 1, d.lds_rows_uv);
-    c.span_y = min(c.f.xhi - c.f.xlo + 1, d.lds_span_y);
-    c.span_uv = min(2 * (c.f.cxhi - c.f.cxlo + 1), d.lds_span_uv);
-}
-
-template <bool AREAUP, int OUT>
-__global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_persistent_kernel(const LaunchDesc d, const FrameTable t) {
-    using T = typename OutT<OUT>::type;
-    constexpr int MODE = AREAUP ? M_AREA_UP : M_BILINEAR;
-    const int nthreads = d.tx * d.ty;
-    const int tw = d.tx * PXW, th = d.ty * PXH;
-    const int total = d.tiles_x * d.tiles_y * d.n_frames;
-    const int cw = d.src_w >> 1, chh = d.src_h >> 1;
-    const int y_bytes = d.lds_rows_y * d.lds_cpr_y * 16, uv_bytes = d.lds_rows_uv * d.lds_cpr_uv * 16;
-    const int tab_bytes = (tw + (tw >> 1)) * (int)sizeof(XEntry) + (th + (th >> 1)) * (int)sizeof(YEntry);
-    const int set_bytes = y_bytes + uv_bytes + tab_bytes;
-    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-
-    int tile = blockIdx.x;
-    if (tile >= total) return;
-
-    // stream a tile into LDS set `set` (DMA, asynchronous) and build its coordinate tables
-    auto issue = [&](int tl, int set) {
-        uint8_t *ly_ = lds_raw + set * set_bytes, *luv_ = ly_ + y_bytes;
-        XEntry *xtab = (XEntry *)(luv_ + uv_bytes), *cxtab = xtab + tw;
-        YEntry *ytab = (YEntry *)(cxtab + (tw >> 1)), *cytab = ytab + th;
-        TileCtx c;
-        tile_ctx<MODE>(d, t, tl, ly_, luv_, c);
-        stage_plane_dma(ly_, c.ay, c.py, d.pitch_y, c.ny, c.span_y, d.lds_magic_y, nthreads);
-        stage_plane_dma(luv_, c.auv, c.puv, d.pitch_uv, c.nuv, c.span_uv, d.lds_magic_uv, nthreads);
-        const Footprint &f = c.f;
-        const int ntab = tw + (tw >> 1) + th + (th >> 1);
-        for (int e = threadIdx.x; e < ntab; e += nthreads) {
-            int p;
-            float w;
-            if (e < tw) {
-                axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
-                xtab[e] = XEntry{ p - f.xlo, table_weight(d, w) };
-            } else if (e < tw + (tw >> 1)) {
-                const int k = e - tw;
-                axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
-                cxtab[k] = XEntry{ 2 * (p - f.cxlo), table_weight(d, w) };
-            } else if (e < tw + (tw >> 1) + th) {
-                const int k = e - tw - (tw >> 1);
-                axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
-                const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo;
-                ytab[k] = YEntry{ r0 * c.py.lp + ((c.py.m0 + r0 * c.py.pm) & 15), r1 * c.py.lp + ((c.py.m0 + r1 * c.py.pm) & 15), table_weight(d, w), 0 };
-            } else {
-                const int k = e - tw - (tw >> 1) - th;
-                axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
-                const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
-                cytab[k] = YEntry{ r0 * c.puv.lp + ((c.puv.m0 + r0 * c.puv.pm) & 15), r1 * c.puv.lp + ((c.puv.m0 + r1 * c.puv.pm) & 15), table_weight(d, w), 0 };
-            }
-        }
-    };
-
-    issue(tile, 0);
-    int cur = 0;
-    for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA chunks of set `cur` have landed
-        __syncthreads();                                  // ... everybody's, and the tables are visible
-        const int next = tile + (int)gridDim.x;
-        if (next < total) issue(next, cur ^ 1);           // in flight during everything below
-        uint8_t *lds_y = lds_raw + cur * set_bytes, *lds_uv = lds_y + y_bytes;
-        XEntry *xtab = (XEntry *)(lds_uv + uv_bytes), *cxtab = xtab + tw;
-        YEntry *ytab = (YEntry *)(cxtab + (tw >> 1)), *cytab = ytab + th;
-        TileCtx c; // uniform; recomputed rather than carried across the loop
-        tile_ctx<MODE>(d, t, tile, lds_y, lds_uv, c);
-        const Footprint &f = c.f;
-        const bool edge_y = (f.xhi == d.src_w - 1), edge_uv = (f.cxhi == cw - 1);
-        if (edge_y || edge_uv) {
-            if (edge_y)
-                for (int r = threadIdx.x; r < c.ny; r += nthreads) {
-                    uint8_t *q = lds_y + r * c.py.lp + ((c.py.m0 + r * c.py.pm) & 15) + (d.src_w - f.xlo);
-                    q[0] = q[-1];
-                }
-            if (edge_uv)
-                for (int r = threadIdx.x; r < c.nuv; r += nthreads) {
-                    uint8_t *q = lds_uv + r * c.puv.lp + ((c.puv.m0 + r * c.puv.pm) & 15) + 2 * (cw - f.cxlo);
-                    q[0] = q[-2];
-                    q[1] = q[-1];
-                }
-            __syncthreads();
-        }
-        const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-        if (j0 < d.dst_w && i0 < d.dst_h) {
-            if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), rows_from_lds(ytab, cytab, ly), (T *)t.out[c.id.frame], i0, j0);
-            else if (d.bil_win) bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, win_columns(xtab, cxtab, lx), rows_from_lds(ytab, cytab, ly), (T *)t.out[c.id.frame], i0, j0);
-            else if (d.bil_int) bilinear_int_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
-            else bilinear_thread_tile<OUT>(d, lds_y, lds_uv, xtab, cxtab, ytab, cytab, lx, ly, (T *)t.out[c.id.frame], i0, j0);
-        }
-        if (next >= total) break;
-        tile = next;
-        cur ^= 1;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
 // Host side of the geometry tables.
 struct GeoHost {
     std::vector<int4> tx, ty;
@@ -828,12 +674,11 @@ static hipError_t launch_bilinear_geo(OutKind out, const LaunchDesc &d, const Fr
 }
 
 template <bool AREAUP>
-static hipError_t launch_bilinear_a(OutKind out, bool persistent, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+static hipError_t launch_bilinear_a(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     switch (out) {
 #define TSVPP_BIL(O)                                                                                                            \
     case O:                                                                                                                     \
-        if (persistent) hipLaunchKernelGGL((vpp_bilinear_persistent_kernel<AREAUP, O>), grid, block, lds, stream, d, t);         \
-        else hipLaunchKernelGGL((vpp_bilinear_kernel<AREAUP, O>), grid, block, lds, stream, d, t);                              \
+        hipLaunchKernelGGL((vpp_bilinear_kernel<AREAUP, O>), grid, block, lds, stream, d, t);                                   \
         break;
         TSVPP_BIL(O_U8_PLANAR) TSVPP_BIL(O_U8_MERGED) TSVPP_BIL(O_F32_PLANAR) TSVPP_BIL(O_F32_MERGED) TSVPP_BIL(O_NV12_U8)
         TSVPP_BIL(O_NV12_F32) TSVPP_BIL(O_Y800_U8) TSVPP_BIL(O_Y800_F32) TSVPP_BIL(O_HSV_F32)
@@ -843,7 +688,7 @@ static hipError_t launch_bilinear_a(OutKind out, bool persistent, const LaunchDe
     return hipGetLastError();
 }
 
-hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &din, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
+hipError_t launch_bilinear(bool areaup, OutKind out, const LaunchDesc &din, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
                            hipStream_t stream, LaunchInfo *info) {
     LaunchDesc d = din;
     dim3 grid(grid_x), block((unsigned)(d.tx * d.ty));
@@ -857,7 +702,7 @@ hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const Laun
     // only; TSVPP_GEO=2 forces the tables wherever they apply, TSVPP_GEO=0 disables them.
     const bool u8_out = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
     const bool geo_want = d.geo_pref == 2 || (d.geo_pref == 1 && u8_out && d.bil_int == 2);
-    const bool geo_ok = !persistent && geo_want && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
+    const bool geo_ok = geo_want && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
     if (geo_ok) {
         if (d.geo_cache) d.geo = geo_lookup(d.geo_cache, areaup, d, stream, !info || d.geo_build, d) ? 1 : 0;
         else if (info) { // tsvpp_describe: no device -- eligibility only
@@ -870,16 +715,15 @@ hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const Laun
         lds_bytes -= (cols + cols / 2) * sizeof(XEntry) + (rows + rows / 2) * sizeof(YEntry);
     }
     if (info) {
-        info->kernel = persistent ? (areaup ? "vpp_bilinear_persistent_kernel<areaup,OUT>" : "vpp_bilinear_persistent_kernel<bilinear,OUT>")
-                                  : (areaup ? "vpp_bilinear_kernel<areaup,OUT>" : "vpp_bilinear_kernel<bilinear,OUT>");
+        info->kernel = areaup ? "vpp_bilinear_kernel<areaup,OUT>" : "vpp_bilinear_kernel<bilinear,OUT>";
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         info->geo = d.geo;
         return hipSuccess;
     }
     if (d.geo) return launch_bilinear_geo(out, d, t, grid, block, lds_bytes, stream);
-    return areaup ? launch_bilinear_a<true>(out, persistent, d, t, grid, block, lds_bytes, stream)
-                  : launch_bilinear_a<false>(out, persistent, d, t, grid, block, lds_bytes, stream);
+    return areaup ? launch_bilinear_a<true>(out, d, t, grid, block, lds_bytes, stream)
+                  : launch_bilinear_a<false>(out, d, t, grid, block, lds_bytes, stream);
 }
 
 } // namespace tsvpp

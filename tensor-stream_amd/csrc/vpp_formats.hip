@@ -411,9 +411,8 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444_rp(const FrameTable
 
 hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int py, int puv, int w, int h, hipStream_t stream) {
     // row-pair kernels: PX pixels per thread (see above); the input alignment they need is PX bytes, the output's 16
-    static const int rp_pref = [] { const char *e = std::getenv("TSVPP_FMT_RP"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = single-row kernels
     const int px = fourcc == TSVPP_UYVY ? (f32 ? 2 : 8) : (f32 ? 4 : 16);
-    bool rp = rp_pref != 0 && (fourcc == TSVPP_UYVY || fourcc == TSVPP_YUV444) && (w % px) == 0 && (h % 2) == 0 && (py % px) == 0 && (puv % px) == 0 &&
+    bool rp = (fourcc == TSVPP_UYVY || fourcc == TSVPP_YUV444) && (w % px) == 0 && (h % 2) == 0 && (py % px) == 0 && (puv % px) == 0 &&
               w >= 2 * px;
     for (int f = 0; f < n && rp; f++)
         rp = ((uintptr_t)t.out[f] & 15) == 0 && (((uintptr_t)t.y[f] | (uintptr_t)t.uv[f]) & (uintptr_t)(px - 1)) == 0;

@@ -87,15 +87,13 @@ struct LaunchDesc {
     float area_direct_min;  // use it when both ratios are >= this (0 = never)
     float area_direct_fmin; // the same for the float-weight direct kernel
     int rpt_pref;           // preferred row pairs per thread for the 2x2-tap kernel (TSVPP_RPT)
-    int dma_pow2;           // A/B only: LDS-DMA rows padded to a power-of-two number of chunks (the round-1 layout)
     int dma;                // 1 = stage with LDS-DMA (global_load_lds_dwordx4) where the kernel supports it
-    int persist;            // 1 = persistent double-buffered kernel for the 2x2-tap family (when it fits)
-    int num_cus;            // compute units of the device (persistent grid sizing)
+    int num_cus;            // compute units of the device (how many workgroups a launch should have)
     int box_rx, box_ry;     // host: the AREA weight table of that axis is one row of all ones (integer ratio) -> its tap count, else 0
     int area_box_pref, area_box; // contiguous-run box kernel allowed (TSVPP_AREA_BOX) / chosen by launch_fused
     int w_dyadic;           // host: every interpolation weight of this BILINEAR / BICUBIC / AREA-up request is a multiple of 1/16
     int bil_int_pref, bil_int; // integer 2x2-tap thread tile allowed (TSVPP_BILINEAR_INT) / chosen by launch_fused
-    int bil_win_pref, bil_win;   // window form of the float 2x2-tap thread tile allowed (TSVPP_BILINEAR_WIN) / chosen by launch_fused
+    int bil_win_pref, bil_win;   // window form of the float 2x2-tap thread tile allowed (where it measured faster) / chosen by launch_fused
     int u8_xchg;                 // uint8 merged outputs: in-wave LDS exchange -> 16-byte stores (TSVPP_U8_XCHG)
     int bicubic_int_pref, bicubic_int; // integer BICUBIC kernel allowed (TSVPP_BICUBIC_INT) / chosen by launch_fused
     int hcs_y, hcs_uv;      // integer BICUBIC kernel: byte stride of one column of the column-major H planes
@@ -105,7 +103,6 @@ struct LaunchDesc {
     int col0;               // first output column of this launch (0; dst_w & ~3 in the row-tail launch of widths 4 k + 2)
     int lds_budget_kb;      // LDS bytes a workgroup may use for staging + tables (default 40 KiB: four workgroups per CU)
     int luma_only;          // Y800 outputs: the chroma plane is neither staged nor sampled
-    int ablate;             // profiling only (TSVPP_ABLATE): 1 no stores, 2 no staging loads, 4 no arithmetic
     // Host-built geometry tables of the 2x2-tap kernel's window tiles (vpp_bilinear.hip, "geometry tables"): tile footprints
     // (scalar loads), one record per output column quad and per output row pair.  geo_pref: allowed (TSVPP_GEO); geo: chosen
     // by launch_bilinear; geo_build: a dry run (info != nullptr) still builds / uploads the tables (tsvpp_prepare_batch);
@@ -126,8 +123,8 @@ struct LaunchDesc {
     const BcEntry *bc_tab;
     int bc_npy, bc_npc;
     // float-weight AREA down-scale, one wave per tile with the source rows streamed through a wave-private LDS ring (vpp_area_stream.hip):
-    // allowed (TSVPP_AREA_STREAM) / chosen by launch_fused; as_nk: its instantiated tap count / 4 (>= nkx); as_rows: forced tile height (4 / 8,
-    // TSVPP_AREA_STREAM_ROWS).  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
+    // allowed (TSVPP_AREA_STREAM) / chosen by launch_fused; as_nk: its instantiated tap count / 4 (>= nkx); as_rows / as_min_taps: its tile height (4) and
+    // cross-over (40 taps per value), constants since the A/B runs of round 3.  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
     int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_two; // as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
     int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
     GeoCache *geo_cache;
@@ -189,8 +186,8 @@ hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t
 // BILINEAR at exactly 3 : 2 on both axes, uint8 outputs, straight from global memory (vpp_bilinear_r32.hip).
 hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
-// The 2x2-tap kernel family (vpp_bilinear.hip): BILINEAR / AREA up-scale, plain or persistent.
-hipError_t launch_bilinear(bool areaup, OutKind out, bool persistent, const LaunchDesc &d, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
+// The 2x2-tap kernel family (vpp_bilinear.hip): BILINEAR / AREA up-scale.
+hipError_t launch_bilinear(bool areaup, OutKind out, const LaunchDesc &d, const FrameTable &t, unsigned grid_x, size_t lds_bytes,
                            hipStream_t stream, LaunchInfo *info);
 
 // UYVY / YUV444 from n (<= TSVPP_MAX_BATCH) NV12 frames of one geometry in one launch (vpp_formats.hip);

@@ -44,41 +44,6 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_gather_kernel(const Lau
 
 
 // ----------------------------------------------------------------------------------------------
-// Generic staged kernel (NEAREST, BICUBIC, AREA-down): footprint in LDS, generic samplers.
-template <int MODE, int OUT>
-__global__ __launch_bounds__(MAX_THREADS) void vpp_fused_staged_kernel(const LaunchDesc d, const FrameTable t) {
-    using T = typename OutT<OUT>::type;
-    const TileId id = decode_tile(d);
-    if (!id.valid) return;
-    const int nthreads = d.tx * d.ty;
-    const Footprint f = tile_footprint<MODE>(d, id);
-
-    LdsSrc s;
-    s.w = d.src_w;
-    s.h = d.src_h;
-    uint8_t *lds_uv = lds_raw + d.lds_rows_y * d.lds_cpr_y * 16;
-    const uint8_t *ay, *auv;
-    s.py_ = describe_plane(lds_raw, t.y[id.frame], d.pitch_y, f.ylo, f.xlo, d.lds_cpr_y, ay);
-    s.puv_ = describe_plane(lds_uv, t.uv[id.frame], d.pitch_uv, f.cylo, 2 * f.cxlo, d.lds_cpr_uv, auv);
-    const int ny = min(f.yhi - f.ylo + 1, d.lds_rows_y), nuv = d.luma_only ? 0 : min(f.cyhi - f.cylo + 1, d.lds_rows_uv);
-    const int spy = min(f.xhi - f.xlo + 1, d.lds_span_y), spuv = min(2 * (f.cxhi - f.cxlo + 1), d.lds_span_uv);
-    if (d.dma) {
-        stage_plane_dma(lds_raw, ay, s.py_, d.pitch_y, ny, spy, d.lds_magic_y, nthreads);
-        stage_plane_dma(lds_uv, auv, s.puv_, d.pitch_uv, nuv, spuv, d.lds_magic_uv, nthreads);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        stage_planes<4, 2>(d, lds_raw, ay, s.py_, ny, spy, lds_uv, auv, s.puv_, nuv, spuv, nthreads);
-    }
-    __syncthreads();
-
-    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = f.j_first + lx * PXW, i0 = f.i_first + ly * PXH;
-    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
-    convert_thread_tile<MODE, OUT, true>(s, d, (T *)t.out[id.frame], i0, j0);
-}
-
-// ----------------------------------------------------------------------------------------------
 // AREA down-scale with float (non-dyadic) weights and RX x RY <= 3 x 3 taps -- ratios below 3 on both axes that the
 // integer kernels cannot take (4/3: 1440p -> 1080p; 2.25 x 1.69: 1080x608 -> 480x360; 2.4; ...).  The 2x2-tap skeleton
 // once more -- staged footprint, per-workgroup tables, float pairs -- with the reference's weighted box instead of
@@ -968,13 +933,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     }
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
-            // persistent variant: two LDS tile sets filled by LDS-DMA
-            if (d.persist > 0 && d.dma && 2 * lds_bytes <= 64 * 1024 && (d.dst_w & 3) == 0) { // (no row-tail path in that kernel)
-                const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
-                const long resident = (long)d.num_cus * d.persist;
-                return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, true, d, t, (unsigned)(total < resident ? total : resident), 2 * lds_bytes, stream, info);
-            }
-            return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, false, d, t, grid.x, lds_bytes, stream, info);
+            return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, d, t, grid.x, lds_bytes, stream, info);
         }
     } else if constexpr (MODE == M_BICUBIC) {
         if (d.bicubic_cols) return launch_bicubic_cols((OutKind)OUT, d.bicubic_cols == 2, d, t, lds_bytes, stream, info);
@@ -1028,10 +987,6 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
                 return info ? hipSuccess : hipGetLastError();
             }
         }
-        if (staged) {
-            TSVPP_LAUNCH("vpp_fused_staged_kernel<MODE, OUT>", (vpp_fused_staged_kernel<MODE, OUT>), grid, block, lds_bytes);
-            return info ? hipSuccess : hipGetLastError();
-        }
     } else {
         if (staged) { // colour-only fast path ("staged" = eligible)
             TSVPP_LAUNCH("vpp_color_kernel<OUT>", (vpp_color_kernel<OUT>), grid, block, 0);
@@ -1070,7 +1025,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form
     if (d.bil_int && d.bil_int_pref != 2 && d.xr <= 2.0f) d.bil_int = 2;
     // float weights, same windows: measured +4..6 % at ratios 1.2 / 1.4 (1080p -> 1600x900, 1366x768), -2..5 % at 1.5 x 1.27 and 1.92,
-    // even below 1 (profiles/r02_bilinear_winf_ab.txt) -- used between 1 and 1.45; TSVPP_BILINEAR_WIN=2 forces it wherever it applies
+    // even below 1 (profiles/r02_bilinear_winf_ab.txt) -- used between 1 and 1.45
     d.bil_win = (!d.bil_int && (mode == M_BILINEAR || mode == M_AREA_UP) && d.xr <= 2.0f &&
                  (d.bil_win_pref == 2 || (d.bil_win_pref == 1 && d.xr > 1.0f && d.xr <= 1.45f))) ? 1 : 0;
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
@@ -1146,7 +1101,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.area_stream = 0;
     size_t as_lds = 0;
     // TSVPP_AREA_STREAM: 1 = from `as_min_taps` taps per value on (measured cross-over, profiles/r03_area_stream_ab*.txt), 2 = wherever it applies
-    if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && (d.area_stream_pref == 2 || (d.area_stream_pref == 1 && (d.rx * d.ry >= d.as_min_taps || d.nkx > 3))) && d.area_div && d.patx4 && d.paty4 && d.nkx >= 1 && d.nkx <= 8 &&
+    if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && (d.area_stream_pref == 2 ||
+         (d.area_stream_pref == 1 && (d.rx * d.ry >= d.as_min_taps || d.nkx > 3 || (d.area_direct != 2 && !(d.rx <= 3 && d.ry <= 3 && d.area2_pref))))) && d.area_div && d.patx4 && d.paty4 && d.nkx >= 1 && d.nkx <= 8 &&
         (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0) {
         const int nk = d.nkx <= 4 ? d.nkx : (d.nkx <= 6 ? 6 : 8);
         auto rowb_of = [&](int cols) {
@@ -1229,13 +1185,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             const bool bint = bicubic_staged; // dyadic weights: integer kernel
             const bool area2 = mode == M_AREA_DOWN && !(d.qx && d.qy) && d.rx >= 2 && d.rx <= 3 && d.ry >= 2 && d.ry <= 3 && d.area2_pref;
             const bool dyadic = mode == M_AREA_DOWN && d.qx && d.qy;
+            if ((mode == M_AREA_DOWN && !dyadic && !area2) || mode == M_NEAREST) break; // (no staged kernel: streaming kernel above, or gathers)
             // Row pairs per thread (TSVPP_RPT; 0 = per kernel).  Taller thread tiles amortise the tile decode, staging set-up and
             // table build over more pixels -- that pays where the kernel is VALU-bound (uint8 outputs, separable BICUBIC, the
             // AREA kernels: two row pairs) -- but the fp32 2x2-tap kernel is bound by the HBM write pattern, which prefers
             // SHORT tiles (round 2 sweep: one row pair wins by 2..9 % on 1080p -> 720p, 4K -> 1080p and 720p -> 1080p).
             const int rpt_auto = (two_tap && f32_out) ? 1 : 2;
             const int rpt_want = d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : rpt_auto;
-            int rpt_max = ((two_tap && !d.persist) || bint || area2 || dyadic) ? rpt_want : 1;
+            int rpt_max = (two_tap || bint || area2 || dyadic) ? rpt_want : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups
             // (8 per CU): small outputs (C3: 256x256) need the parallelism more than the amortisation
             // (the 2x2-tap kernel wants six rounds)
@@ -1258,10 +1215,6 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
                 c.rows_uv = rows_uv;
                 c.dma = (layout == 1 && nthreads >= 64) ? 1 : 0;
                 if (layout == 1 && !c.dma) return c;
-                if (c.dma && d.dma_pow2) { // round-1 layout (A/B: TSVPP_DMA_POW2=1): power-of-two chunks per row
-                    c.cpr_y = 1 << slot_shift_for(c.cpr_y);
-                    c.cpr_uv = 1 << slot_shift_for(c.cpr_uv);
-                }
                 if (c.dma) { // a wave instruction fills 64 consecutive chunk slots: the plane is allocated up to a multiple of 64 slots
                     c.rows_y = ((rows_y * c.cpr_y + 63) / 64 * 64 + c.cpr_y - 1) / c.cpr_y;
                     c.rows_uv = ((rows_uv * c.cpr_uv + 63) / 64 * 64 + c.cpr_uv - 1) / c.cpr_uv;

@@ -77,7 +77,7 @@ def test_streaming_kernel_pitch_crop_flavours(vpp, oracle):
         run(vpp, oracle, y, uv, 1920, (100, 96), fourcc=fourcc, planes=planes, norm=norm)   # 19.2 x 11.25: 64-column tiles
 
 
-@pytest.mark.parametrize("env", [{"TSVPP_AREA_STREAM": "2"}, {"TSVPP_AREA_STREAM": "2", "TSVPP_AREA_STREAM_ROWS": "8"}, {"TSVPP_AREA_STREAM": "0"}])
+@pytest.mark.parametrize("env", [{"TSVPP_AREA_STREAM": "2"}, {"TSVPP_AREA_STREAM": "0"}])
 def test_streaming_kernel_forced_everywhere_and_off(oracle, env, monkeypatch):
     """TSVPP_AREA_STREAM=2: every float-weight AREA down-scale (2 x 2 taps upward) on the streaming kernel; =0: none (round-2 kernels)."""
     import tensor_stream as ts

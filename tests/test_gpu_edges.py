@@ -211,16 +211,16 @@ def test_area_dyadic_lds_kernel_ratios_2_to_3p5(vpp, oracle, src, dst):
     conv(vpp, oracle, y, uv, width=src[0], crop=(2, 2, src[0] - 2, src[1] - 2), dst=dst, rt=3, planes=1, norm=False)
 
 
-@pytest.mark.parametrize("fmin", [None, "3"])
-def test_area_float_kernel_up_to_3x3_taps(oracle, monkeypatch, fmin):
-    """Non-dyadic AREA with 2 or 3 taps per axis in every combination (3x2, 2x3, 3x3): the LDS float kernel; with
-    TSVPP_AREA_DIRECT_FMIN=3 also the 3x3 cases that the direct float kernel takes by default."""
+@pytest.mark.parametrize("stream", [None, "2"])
+def test_area_float_kernel_up_to_3x3_taps(oracle, monkeypatch, stream):
+    """Non-dyadic AREA with 2 or 3 taps per axis in every combination (3x2, 2x3, 3x3): the LDS float kernel / the direct float
+    kernel; with TSVPP_AREA_STREAM=2 the streaming kernel takes them all (pitches that are multiples of 16)."""
     import tensor_stream as ts
-    if fmin:
-        monkeypatch.setenv("TSVPP_AREA_DIRECT_FMIN", fmin)
+    if stream:
+        monkeypatch.setenv("TSVPP_AREA_STREAM", stream)
     v = ts.VideoProcessor(device=0, max_consumers=2)
     try:
-        y, uv = synth_nv12(1080, 608, seed=99, pitch=1091)
+        y, uv = synth_nv12(1080, 608, seed=99, pitch=1104 if stream else 1091)
         for dst in [(480, 360), (640, 224), (452, 256), (400, 240), (364, 380)]:
             conv(v, oracle, y, uv, width=1080, dst=dst, rt=3, planes=0, norm=True)
             conv(v, oracle, y, uv, width=1080, crop=(1, 2, 1079, 606), dst=dst, rt=3, planes=1, norm=False)
