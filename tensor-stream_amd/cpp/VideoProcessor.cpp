@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <iostream>
+#include <mutex>
 #include <thread>
 
 namespace {
@@ -46,6 +47,103 @@ float channelsByFourCC(std::string fourCC) {
     if (fourCC == "NV12") return 1.5f;
     return 3;
 }
+
+// ---- stage launchers ------------------------------------------------------------------------------------------------------
+namespace {
+// one context per device for the free functions (the class owns its own): created on first use, lives as long as the process
+tsvpp_ctx *stage_ctx() {
+    static std::mutex mu;
+    static tsvpp_ctx *ctxs[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ctxs[dev] && tsvpp_create(dev, 1, &ctxs[dev]) != 0) ctxs[dev] = nullptr;
+    return ctxs[dev];
+}
+// NV12 stage: `in` -> tight NV12 of the request's output size, handed out as TWO device buffers the caller frees one by one
+// (the reference's cudaMalloc pair): the conversion writes Y and UV into one buffer, the UV part moves to its own
+int nv12_stage(const tsvpp_nv12 &in, tsvpp_params p, AVFrame *dst, hipStream_t stream) {
+    tsvpp_ctx *ctx = stage_ctx();
+    if (!ctx) CHECK_STATUS(VREADER_ERROR);
+    p.fourcc = TSVPP_NV12;
+    p.planes = TSVPP_PLANAR;
+    p.normalization = 0;
+    int w = 0, h = 0;
+    CHECK_STATUS(tsvpp_out_dims(&p, in.width, in.height, &w, &h));
+    uint8_t *y = nullptr, *uv = nullptr;
+    CHECK_STATUS((int)hipMalloc((void **)&y, (size_t)w * h * 3 / 2));
+    if (hipMalloc((void **)&uv, (size_t)w * h / 2) != hipSuccess) {
+        (void)hipFree(y);
+        CHECK_STATUS(VREADER_ERROR);
+    }
+    int sts = tsvpp_convert(ctx, &in, &p, y, stream);
+    if (sts == 0) sts = (int)hipMemcpyAsync(uv, y + (size_t)w * h, (size_t)w * h / 2, hipMemcpyDeviceToDevice, stream);
+    if (sts != 0) {
+        (void)hipFree(y);
+        (void)hipFree(uv);
+        CHECK_STATUS(sts);
+    }
+    dst->data[0] = y;
+    dst->data[1] = uv;
+    return VREADER_OK;
+}
+} // namespace
+
+int cropHost(AVFrame *src, AVFrame *dst, CropOptions crop, int, hipStream_t *stream) {
+    if (!src || !dst || !stream) CHECK_STATUS(VREADER_ERROR);
+    const int left = std::get<0>(crop.leftTopCorner), top = std::get<1>(crop.leftTopCorner);
+    const int cw = std::get<0>(crop.rightBottomCorner) - left, ch = std::get<1>(crop.rightBottomCorner) - top;
+    const int py = src->linesize[0] ? src->linesize[0] : src->width, puv = src->linesize[1] ? src->linesize[1] : src->width;
+    if (cw <= 0 || ch <= 0 || left < 0 || top < 0) CHECK_STATUS(VREADER_ERROR);
+    // the reference's cropKernel IS pointer arithmetic: luma (left + j, top + i), chroma row top / 2 + i / 2, chroma byte (j & ~1) + left
+    // (an odd `left` swaps U and V there too, src/Crop.cu:10-18) -- so the box is described as a frame of its own, whatever its size
+    const tsvpp_nv12 in{ src->data[0] + (size_t)top * py + left, src->data[1] + (size_t)(top / 2) * puv + left, py, puv, cw, ch };
+    tsvpp_params p{}; // no crop, no resize: the planes themselves
+    return nv12_stage(in, p, dst, *stream);
+}
+
+int resizeKernel(AVFrame *src, AVFrame *dst, bool crop, ResizeOptions resize, int, hipStream_t *stream) {
+    if (!src || !dst || !stream) CHECK_STATUS(VREADER_ERROR);
+    uint8_t *old_y = src->data[0], *old_uv = src->data[1]; // (src and dst may be the same AVFrame: VideoProcessor::Convert does that)
+    const tsvpp_nv12 in{ old_y, old_uv, src->linesize[0] ? src->linesize[0] : src->width, src->linesize[1] ? src->linesize[1] : src->width, src->width, src->height };
+    tsvpp_params p{};
+    p.dst_width = (int)resize.width;
+    p.dst_height = (int)resize.height;
+    p.resize_type = (int)resize.type;
+    CHECK_STATUS(nv12_stage(in, p, dst, *stream));
+    if (crop) { // the input was cropHost's pair (reference src/Resize.cu:465-468; hipFree waits for the work above)
+        CHECK_STATUS((int)hipFree(old_y));
+        CHECK_STATUS((int)hipFree(old_uv));
+    }
+    return VREADER_OK;
+}
+
+template <class T> int colorConversionKernel(AVFrame *src, AVFrame *dst, ColorOptions color, int, hipStream_t *stream) {
+    if (!src || !dst || !stream) CHECK_STATUS(VREADER_ERROR);
+    tsvpp_ctx *ctx = stage_ctx();
+    if (!ctx) CHECK_STATUS(VREADER_ERROR);
+    const bool f32 = color.normalization || color.dstFourCC == FourCC::HSV;
+    if (f32 != (sizeof(T) == sizeof(float))) CHECK_STATUS(VREADER_UNSUPPORTED); // Convert() picks <float> iff normalization
+    const int w = dst->width, h = dst->height;
+    const tsvpp_nv12 in{ src->data[0], src->data[1], src->linesize[0] ? src->linesize[0] : w, src->linesize[1] ? src->linesize[1] : w, w, h };
+    tsvpp_params p{};
+    p.fourcc = (int)color.dstFourCC;
+    p.planes = (int)color.planesPos;
+    p.normalization = color.normalization ? 1 : 0;
+    const size_t bytes = tsvpp_out_bytes(&p, w, h);
+    if (bytes == 0) CHECK_STATUS(VREADER_UNSUPPORTED);
+    void *out = nullptr;
+    CHECK_STATUS((int)hipMalloc(&out, bytes));
+    const int sts = tsvpp_convert(ctx, &in, &p, out, *stream);
+    if (sts != 0) {
+        (void)hipFree(out);
+        CHECK_STATUS(sts);
+    }
+    dst->opaque = out;
+    return VREADER_OK;
+}
+template int colorConversionKernel<float>(AVFrame *, AVFrame *, ColorOptions, int, hipStream_t *);
+template int colorConversionKernel<unsigned char>(AVFrame *, AVFrame *, ColorOptions, int, hipStream_t *);
 
 int VideoProcessor::Init(std::shared_ptr<Logger> log, uint8_t maxConsumers, bool dumps, int device) {
     if (!isClosed) Close();

@@ -40,6 +40,8 @@ inline void av_frame_unref(AVFrame *f) { if (f) *f = AVFrame(); }
 inline void av_frame_free(AVFrame **f) { if (f && *f) { delete *f; *f = nullptr; } }
 #endif
 
+#include <hip/hip_runtime.h>
+
 #include "tsvpp.h"
 
 // ---- reference include/Common.h:19-24, 29-34, 62-70 -------------------------------------------
@@ -82,6 +84,22 @@ struct FrameParameters {
 
 float channelsByFourCC(FourCC fourCC);
 float channelsByFourCC(std::string fourCC);
+
+// ---- the reference's public stage launchers (include/VideoProcessor.h:110-115), source-compatible ----------------------
+// The fused kernels have no stages; these thin functions run ONE stage each through the same C ABI (NV12 in, NV12 out for
+// crop / resize) with the reference's buffer contract, so code that called the stages directly keeps compiling and the stages
+// can be compared one by one (tests/test_cpp_stages_gpu.py).  `maxThreadsPerBlock` is accepted and ignored; the work is
+// enqueued on *stream of the calling thread's current device (a process-wide context per device, created on first use).
+//   cropHost:      dst->data[0] / data[1] = fresh device buffers (cw * ch, cw * ch / 2) holding the box; dst sizes / linesize untouched
+//                  (reference src/Crop.cu:23-48; the caller sets dst->width / height and later hipFree()s both buffers)
+//   resizeKernel:  src->width / height / linesize (0 = width) describe the input; dst->data[0] / data[1] = fresh buffers of
+//                  resize.width x resize.height; `crop` = the input buffers came from cropHost and are freed here (src/Resize.cu:408-473)
+//   colorConversionKernel<T>: input = src planes of dst->width x dst->height (pitch src->linesize[0] or that width);
+//                  dst->opaque = fresh buffer of channels * w * h elements of T (src/ColorConversion.cu:280-382); T = float iff
+//                  color.normalization (or HSV), as VideoProcessor::Convert calls it
+int cropHost(AVFrame *src, AVFrame *dst, CropOptions crop, int maxThreadsPerBlock, hipStream_t *stream);
+int resizeKernel(AVFrame *src, AVFrame *dst, bool crop, ResizeOptions resize, int maxThreadsPerBlock, hipStream_t *stream);
+template <class T> int colorConversionKernel(AVFrame *src, AVFrame *dst, ColorOptions color, int maxThreadsPerBlock, hipStream_t *stream);
 
 class VideoProcessor {
 public:
