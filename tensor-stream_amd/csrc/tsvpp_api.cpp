@@ -35,8 +35,21 @@ struct AreaTable {
     int uniform_sum = 0;      // > 0: every row of the integer table has this weight sum
     float *dev4 = nullptr;    // the float rows zero-padded to a multiple of four taps
     int nk = 0;               // taps4 = 4 * nk
+    int ones_end = 0;         // taps 1 .. ones_end - 1 weigh exactly 1.0f in every row (the streaming kernel multiplies nothing there)
     std::shared_ptr<std::vector<float>> host4; // host copy of dev4 (divisor tables of the float AREA kernels)
 };
+
+// Largest E such that taps 1 .. E - 1 weigh exactly 1.0f in every row of a weight table (the reference's rows are [rest] 1 ... 1 [last
+// fraction]: E >= taps - 1 or taps - 2).
+int area_ones_end(const std::vector<float> &tab, int rows, int taps) {
+    int end = taps;
+    for (int r = 0; r < rows; r++) {
+        int k = 1;
+        while (k < end && tab[(size_t)r * taps + k] == 1.0f) k++;
+        end = k;
+    }
+    return end;
+}
 
 // Integer form of a weight table if all weights are dyadic: w * 2^shift integral, shift <= 6.
 bool quantise_area_rows(const std::vector<float> &tab, int rows, int taps, std::vector<AreaQRow> &q, int &shift) {
@@ -402,6 +415,7 @@ int get_area_table(tsvpp_ctx *ctx, float scale, AreaTable &out) {
     }
     {
         t.nk = (t.taps + 3) / 4;
+        t.ones_end = area_ones_end(tab, t.rows, t.taps);
         std::vector<float> pad((size_t)t.rows * 4 * t.nk, 0.0f);
         for (int r = 0; r < t.rows; r++)
             for (int k = 0; k < t.taps; k++) pad[(size_t)r * 4 * t.nk + k] = tab[(size_t)r * t.taps + k];
@@ -784,6 +798,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         d.nkx = tx.nk;
         d.paty4 = ty.dev4;
         d.nky = ty.nk;
+        d.as_ones_x = tx.ones_end;
         if (!(tx.qdev && ty.qdev) && ctx->area_divtab) { // float-weight kernels only
             sts = get_area_div(ctx, pl.xr, pl.yr, tx, ty, d.area_div, (hipStream_t)stream);
             if (sts != TSVPP_OK) return sts;
@@ -931,6 +946,7 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
             (axis ? d.ny : d.nx) = rows;
             (axis ? d.ry : d.rx) = taps;
             (axis ? d.nky : d.nkx) = (taps + 3) / 4;
+            if (axis == 0) d.as_ones_x = area_ones_end(tab, rows, taps);
         }
         d.patx = d.paty = d.patx4 = d.paty4 = dummy_f;
         if (!(dyadic[0] && dyadic[1]) && tmp.area_divtab && (long)d.nx * d.ny <= (1L << 18)) d.area_div = dummy_f; // as get_area_div would

@@ -29,9 +29,82 @@ namespace tsvpp {
 
 typedef float as_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int AS_RING = 4; // rows of the ring
+constexpr int AS_RING = AS_RING_ROWS; // rows of the ring (vpp_kernels.h)
 
 __device__ __forceinline__ float asb(uint32_t v, int b) { return (float)((v >> (8 * b)) & 255u); }
+
+// The taps of one source row for a lane's two chains (luma: columns A and B; chroma: U and V of one pair column), in tap order.
+// Two facts about the weight rows (build_area_rows, the reference's pattern: [rest] 1 1 ... 1 [last fraction], `taps` = ceil(ratio)
+// entries, zero-padded to 4 * nkx) allow a third less arithmetic without touching a single rounding:
+//   * taps 1 .. taps - 3 are exactly 1.0f in EVERY row of the table (the host checks it: AreaTable::ones_end), so their weight is
+//     the row weight itself (1.0f * wy == wy): no multiply.  At compile time only nkx is known (taps >= 4 * nkx - 3), hence
+//     taps 1 .. 4 * nkx - 5; a row whose own weight is 1.0f (ROW_ONE: every row strictly inside the footprint) multiplies nothing.
+//   * taps >= `taps` have weight 0 (an exact no-op on a non-negative sum): skipped, by wave-uniform branches in the last group(s).
+// Measured (profiles/r03_area_stream_lean_ab.txt): from 17 horizontal taps on (ratios > 16, the instances NK = 6 / 8) this is worth
+// +20 % (4K -> 224 x 224: 0.44 -> 0.53); below, the kernel is bound by its row streaming (without ANY arithmetic it runs 0.64 at
+// 1080p -> 224 x 224 against 0.60 with), and the branches cost more than the multiplies they save (0.60 -> 0.54): AS_LEAN.
+template <int NK> constexpr bool AS_LEAN = NK >= 6;
+
+template <int NK, bool CHROMA, bool ROW_ONE>
+__device__ __forceinline__ void as_row_taps(f2 &acc, const uint32_t *dA, const uint32_t *dB, uint32_t aA, uint32_t aB, const as_f4a4 *wxA, const as_f4a4 *wxB,
+                                            float wy, int taps) {
+    constexpr bool LEAN = AS_LEAN<NK>;
+    constexpr int NKMIN = NK == 6 ? 5 : (NK == 8 ? 7 : NK); // the smallest nkx this instance serves
+    constexpr int ALWAYS = LEAN ? 4 * NKMIN - 3 : 4 * NK;                 // taps below this index exist for every ratio served
+    constexpr int ONES_END = LEAN ? 4 * NKMIN - 4 : 0;               // taps 1 .. ONES_END - 1 weigh 1.0f
+    auto tap = [&](int k, int b, uint32_t va, uint32_t vb) {
+        const int t = 4 * k + b;
+        const float wa = b == 0 ? wxA[k].x : (b == 1 ? wxA[k].y : (b == 2 ? wxA[k].z : wxA[k].w));
+        if constexpr (!CHROMA) {
+            const float wb = b == 0 ? wxB[k].x : (b == 1 ? wxB[k].y : (b == 2 ? wxB[k].z : wxB[k].w));
+            f2 wgt = { wa, wb };
+            if constexpr (!ROW_ONE) {
+                if (t >= 1 && t < ONES_END) wgt = (f2){ wy, wy };
+                else wgt = wgt * (f2){ wy, wy };
+            }
+            acc = __builtin_elementwise_fma((f2){ asb(va, b), asb(vb, b) }, wgt, acc); // colorSum = fma(data, weight, colorSum)
+        } else {
+            float wgt = wa;
+            if constexpr (!ROW_ONE) wgt = (t >= 1 && t < ONES_END) ? wy : wa * wy;
+            const uint32_t qq = (b & 2 ? vb : va) >> (16 * (b & 1)); // va = U0 V0 U1 V1, vb = U2 V2 U3 V3
+            acc = __builtin_elementwise_fma((f2){ (float)(qq & 255u), (float)((qq >> 8) & 255u) }, (f2){ wgt, wgt }, acc);
+        }
+    };
+    auto group = [&](int k, uint32_t &va, uint32_t &vb) {
+        if constexpr (!CHROMA) {
+            va = __builtin_amdgcn_alignbyte(dA[k + 1], dA[k], aA);
+            vb = __builtin_amdgcn_alignbyte(dB[k + 1], dB[k], aB);
+        } else {
+            va = __builtin_amdgcn_alignbyte(dA[2 * k + 1], dA[2 * k], aA);
+            vb = __builtin_amdgcn_alignbyte(dA[2 * k + 2], dA[2 * k + 1], aA);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        if (4 * k + 3 < ALWAYS) {
+            uint32_t va, vb;
+            group(k, va, vb);
+#pragma unroll
+            for (int b = 0; b < 4; b++) tap(k, b, va, vb);
+        } else {
+            if (4 * k < ALWAYS || 4 * k < taps) { // (uniform)
+                uint32_t va, vb;
+                group(k, va, vb);
+                // the chain is serial and the padding is a suffix: the first missing tap ends the row
+                if (4 * k + 0 < ALWAYS || 4 * k + 0 < taps) {
+                    tap(k, 0, va, vb);
+                    if (4 * k + 1 < ALWAYS || 4 * k + 1 < taps) {
+                        tap(k, 1, va, vb);
+                        if (4 * k + 2 < ALWAYS || 4 * k + 2 < taps) {
+                            tap(k, 2, va, vb);
+                            if (4 * k + 3 < taps) tap(k, 3, va, vb);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
 
 // One plane of a wave's tile.  CHROMA = false: lane l owns luma columns jf + l and jf + 64 + l; true: pair column jf + l
 // (jf in pair units), taps two bytes apart, (U, V) share every weight.  i0: first output row (plane grid), nout rows;
@@ -113,12 +186,12 @@ __device__ __forceinline__ void as_plane(const LaunchDesc &d, const uint8_t *fra
             while (hi <= r) issue(hi++); // (only if the ring ran dry: ry > 4 at the start of a tile)
             // row r has landed when at most the rows issued after it are outstanding
             const int ahead = (hi - 1 - r) * ipr; // steady state: 3 rows = 3 or 6 instructions
-            if (ahead >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (ahead == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            switch (ahead < 14 ? ahead : 14) { // (the count is an immediate)
+#define AS_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+                AS_W(14) AS_W(13) AS_W(12) AS_W(11) AS_W(10) AS_W(9) AS_W(8) AS_W(7) AS_W(6) AS_W(5) AS_W(4) AS_W(3) AS_W(2) AS_W(1)
+#undef AS_W
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
             const uint8_t *slot = ring + (r & (AS_RING - 1)) * rowb;
             uint32_t dA[NDW], dB[CHROMA ? 1 : NDW];
             {
@@ -141,33 +214,11 @@ __device__ __forceinline__ void as_plane(const LaunchDesc &d, const uint8_t *fra
                     while (hi < lo + AS_RING && hi <= y_last);
                 }
             }
-            const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyv), a));
-            if constexpr (!CHROMA) {
-#pragma unroll
-                for (int k = 0; k < NK; k++) {
-                    const uint32_t va = __builtin_amdgcn_alignbyte(dA[k + 1], dA[k], aA), vb = __builtin_amdgcn_alignbyte(dB[k + 1], dB[k], aB);
-                    const float wa[4] = { wxA[k].x, wxA[k].y, wxA[k].z, wxA[k].w }, wb[4] = { wxB[k].x, wxB[k].y, wxB[k].z, wxB[k].w };
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const f2 wgt = (f2){ wa[b], wb[b] } * (f2){ wy, wy };
-                        acc = __builtin_elementwise_fma((f2){ asb(va, b), asb(vb, b) }, wgt, acc); // colorSum = fma(data, weight, colorSum)
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < NK; k++) {
-                    const uint32_t v0 = __builtin_amdgcn_alignbyte(dA[2 * k + 1], dA[2 * k], aA);     // U0 V0 U1 V1
-                    const uint32_t v1 = __builtin_amdgcn_alignbyte(dA[2 * k + 2], dA[2 * k + 1], aA); // U2 V2 U3 V3
-                    const float wa[4] = { wxA[k].x, wxA[k].y, wxA[k].z, wxA[k].w };
-                    const uint32_t vv[2] = { v0, v1 };
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const uint32_t qq = vv[b >> 1] >> (16 * (b & 1));
-                        const float wgt = wa[b] * wy;
-                        acc = __builtin_elementwise_fma((f2){ (float)(qq & 255u), (float)((qq >> 8) & 255u) }, (f2){ wgt, wgt }, acc);
-                    }
-                }
-            }
+            // the row weight is wave-uniform (an SGPR): a row inside the footprint has weight exactly 1.0f and its taps use the column
+            // weights as they are (wx * 1.0f == wx)
+            const int wyb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyv), a);
+            if (AS_LEAN<NK> && wyb == 0x3f800000) as_row_taps<NK, CHROMA, true>(acc, dA, dB, aA, aB, wxA, wxB, 1.0f, d.rx);
+            else as_row_taps<NK, CHROMA, false>(acc, dA, dB, aA, aB, wxA, wxB, __builtin_bit_cast(float, wyb), d.rx);
         }
         const uint32_t q0 = (uint32_t)__builtin_truncf(acc.x / div.x), q1 = (uint32_t)__builtin_truncf(acc.y / (CHROMA ? div.x : div.y));
         if constexpr (!CHROMA) {

@@ -10,6 +10,10 @@
 
 #include "tsvpp.h"
 
+#ifndef AS_RING_ROWS
+#define AS_RING_ROWS 4 // source rows in a wave's ring of the streaming AREA kernel (a power of two)
+#endif
+
 namespace tsvpp {
 
 // Resize mode of the fused kernel.  AREA splits in two exactly as the reference's host
@@ -125,7 +129,7 @@ struct LaunchDesc {
     // float-weight AREA down-scale, one wave per tile with the source rows streamed through a wave-private LDS ring (vpp_area_stream.hip):
     // allowed (TSVPP_AREA_STREAM) / chosen by launch_fused; as_nk: its instantiated tap count / 4 (>= nkx); as_rows / as_min_taps: its tile height (4) and
     // cross-over (40 taps per value), constants since the A/B runs of round 3.  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
-    int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_two; // as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
+    int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_ones_x, as_two; // as_ones_x: column taps 1 .. as_ones_x - 1 weigh 1.0f in every table row; as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
     int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
     GeoCache *geo_cache;
 };

@@ -1111,7 +1111,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         };
         const int two = rowb_of(128) <= 2048 ? 1 : 0; // a row segment = at most two DMA instructions (128 chunks)
         const int rowb = rowb_of(two ? 128 : 64);
-        if (rowb <= 2048) {
+        const int nkmin = nk == 6 ? 5 : (nk == 8 ? 7 : nk);
+        // (the kernel skips the multiply of column taps 1 .. 4 * nkmin - 5: they weigh 1.0f for every ratio -- checked against the table itself)
+        if (rowb <= 2048 && d.as_ones_x >= 4 * nkmin - 4) {
             // tile height 4 (measured: 8 rows never win -- 4K -> 608x342 0.618 against 0.572, 1080p -> 160^2 0.59 against 0.47; TSVPP_AREA_STREAM_ROWS=8)
             int r = 4;
             if (d.as_rows == 4 || d.as_rows == 8) r = d.as_rows;
@@ -1119,7 +1121,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             d.area_stream = 1;
             d.as_nk = nk;
             d.as_two = two;
-            d.bc_ring_bytes = 4 * rowb + 16;
+            d.bc_ring_bytes = AS_RING_ROWS * rowb + 16;
             d.bc_wave_bytes = d.bc_ring_bytes + 128 * (r + r / 2);
             as_lds = 4 * (size_t)d.bc_wave_bytes;
             d.area_direct = 0;
@@ -1380,7 +1382,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (d.r32) d.area_stream = 0;
     if (d.area_stream) lds_bytes = as_lds;
     const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
-    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
+    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;

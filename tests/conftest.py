@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A kernel that never returns must fail its test, not eat the box: every GPU test gets a time limit (pytest-timeout, when installed)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def golden():
     """The reference's own fp32 golden files (tests/golden/make_golden.py) + the recovered NV12 input."""
