@@ -752,6 +752,20 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on) {
     return TSVPP_OK;
 }
 
+// UYVY (uint8) behind a resize: does the streaming kernel take it (exact 3 : 2 or 2 : 1, BILINEAR / AREA / NEAREST, dword-aligned planes,
+// width % 8 == 0, height % 4 == 0, 16-byte aligned outputs)?  Asked of launch_fused itself, as a dry run: one set of conditions.
+static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void *const *outs, hipStream_t stream) {
+    if (pl.fourcc != TSVPP_UYVY || pl.f32 || pl.mode == M_NONE) return false;
+    if (outs)
+        for (int f = 0; f < n; f++)
+            if (((uintptr_t)outs[f] & 15) != 0) return false;
+    LaunchDesc dd = d;
+    dd.n_frames = n < TSVPP_MAX_BATCH ? (n > 0 ? n : 1) : TSVPP_MAX_BATCH;
+    FrameTable t = {};
+    LaunchInfo info = {};
+    return launch_fused(pl.mode, O_UYVY_U8, true, dd, t, stream, &info) == hipSuccess;
+}
+
 int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
     if (!ctx || !in || !p || !outs || n < 0) return TSVPP_ERROR;
     if (n == 0) return TSVPP_OK;
@@ -825,11 +839,13 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // Formats other than RGB24/BGR24: the reference feeds its other colour kernels with
     // the resized NV12; here pass 1 (only if there is a resize) writes that intermediate with the
     // fused kernel, pass 2 converts it.  Crop alone needs no pass 1: it is pointer arithmetic.
-    const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
+    // ... unless the streaming 3 : 2 / 2 : 1 kernel takes the request: it writes UYVY (uint8) itself, in one pass (vpp_bilinear_r32.hip)
+    const bool single = single_pass_format(pl, d, n, outs, (hipStream_t)stream);
+    const bool two_pass = (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && !single;
     uint8_t *scratch = nullptr;
     size_t frame_scratch = 0;
     std::unique_lock<std::mutex> scratch_lock; // held until both passes of this call are enqueued
-    if (needs_scratch(pl)) {
+    if (needs_scratch(pl) && !single) {
         frame_scratch = scratch_frame_bytes(pl);
         tsvpp_ctx::ScratchSlot *slot = scratch_slot(ctx, stream);
         scratch_lock = std::unique_lock<std::mutex>(slot->mu);
@@ -838,7 +854,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         if (sts != TSVPP_OK) return sts;
         scratch = slot->buf;
     }
-    const OutKind out_kind = pl.out;
+    const OutKind out_kind = single ? O_UYVY_U8 : pl.out;
     if (two_pass && d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
@@ -957,15 +973,17 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
             if (uniform[0] > 0 && uniform[1] > 0 && (long)uniform[0] * uniform[1] < 4096) d.area_rcp = 1.0f / (float)(uniform[0] * uniform[1]);
         }
     }
-    const bool two_pass = pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444;
+    const bool single = aligned_outputs != 0 && single_pass_format(pl, d, n_frames, nullptr, nullptr);
+    const OutKind out_kind = single ? O_UYVY_U8 : pl.out;
+    const bool two_pass = (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && !single;
     d.n_frames = n_frames < TSVPP_MAX_BATCH ? n_frames : TSVPP_MAX_BATCH;
-    static const char *const out_names[O_COUNT] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32" };
+    static const char *const out_names[O_COUNT_ALL] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32", "uyvy_u8" };
     static const char *const mode_names[M_COUNT] = { "none", "nearest", "bilinear", "bicubic", "area_down", "area_up" };
     LaunchInfo info = {};
     info.kernel = "(none)";
     if (!(two_pass && pl.mode == M_NONE)) {
         FrameTable t = {};
-        hipError_t e = launch_fused(pl.mode, pl.out, aligned_outputs != 0 || two_pass, d, t, nullptr, &info);
+        hipError_t e = launch_fused(pl.mode, out_kind, aligned_outputs != 0 || two_pass, d, t, nullptr, &info);
         if (e != hipSuccess) return (int)e;
     }
     char kname[128]; // the launcher's spelling without blanks: one token per key=value pair
@@ -974,7 +992,7 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
         if (*c != ' ') kname[kn++] = *c;
     kname[kn] = 0;
     std::snprintf(buf, buf_len, "mode=%s out=%s src=%dx%d dst=%dx%d kernel=%s shape=%dx%d rpt=%d dma=%d lds=%d grid=%d tiles=%dx%d frames=%d tail=%d geo=%d%s",
-                  mode_names[pl.mode], out_names[pl.out], pl.src_w, pl.src_h, pl.dst_w, pl.dst_h, kname, info.tx, info.ty, info.rpt, info.dma,
+                  mode_names[pl.mode], out_names[out_kind], pl.src_w, pl.src_h, pl.dst_w, pl.dst_h, kname, info.tx, info.ty, info.rpt, info.dma,
                   info.lds_bytes, info.grid, info.tiles_x, info.tiles_y, d.n_frames, info.tail, info.geo,
                   two_pass ? (pl.fourcc == TSVPP_UYVY ? " pass2=fmt_uyvy" : " pass2=fmt_yuv444") : "");
     return TSVPP_OK;

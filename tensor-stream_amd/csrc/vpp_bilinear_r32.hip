@@ -20,6 +20,7 @@
 // RATIO 4 (template parameter P2 = twice the ratio) is the 2 : 1 case (3840x2160 -> 1920x1080, 1920x1080 -> 960x540) on the same skeleton:
 // 1.5 j + 0.25 becomes 2 j + 0.5 -- taps (2 j, 2 j + 1) with weights (1/2, 1/2) for every index --, a thread's 8 columns are 16 source bytes
 // (dwordx4 loads) and its 4 rows 8 luma / 4 chroma source rows; AREA sums the 2 x 2 box and divides by 4, NEAREST takes tap 2 j.
+// UYVY (uint8) is one more output of the same pass: see the kernel body (the vertical chroma filter needs the tile below's two chroma rows).
 // Outputs: RGB24 / BGR24 uint8 planar (8-byte stores) and merged (24 bytes per lane and row, exchanged through LDS inside the wave so
 // that every store instruction writes a contiguous run), NV12, Y800.  fp32 outputs stay on vpp_bilinear_kernel: it sits on the
 // HBM floor of its write pattern already, and 8 fp32 columns per lane would split every line between two store instructions.
@@ -119,6 +120,49 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         for (int r = 0; r < NCR; r++) r32_load<P2>(pc + (size_t)r * (size_t)d.pitch_uv, cs[r]);
     }
 
+    if constexpr (OUT == O_UYVY_U8) {
+        // UYVY (4:2:2) of the resized frame in the same pass (reference src/ColorConversion.cu:107-127, 177-209 on the resized NV12): luma rows
+        // 2 r, 2 r + 1 take chroma row r as it is when r is even and clamp((9 (c[r] + c[r+1]) - (c[r-1] + c[r+2]) + 8) >> 4) when r is odd (rows
+        // clamped to the last).  The tile's chroma rows are r = 2 n4 (even) and 2 n4 + 1 (odd): the odd one needs the two chroma rows of the tile
+        // BELOW -- NCR more source rows of this thread's run (they are the next thread row's loads: cache hits), evaluated here a second time.
+        const bool below = i0 + R32_ROWS < d.dst_h; // (dst_h is a multiple of 4: the tile below is whole or absent)
+        uint32_t cn[NCR][P2];
+        {
+            const uint8_t *pc = t.uv[id.frame] + (size_t)(NCR * (n4 + (below ? 1 : 0))) * (size_t)d.pitch_uv + (size_t)(RUN * q);
+#pragma unroll
+            for (int r = 0; r < NCR; r++) r32_load<P2>(pc + (size_t)r * (size_t)d.pitch_uv, cn[r]);
+        }
+        float c0[8], c1[8], c2[8], c3[8], cf[8];
+        r32_row<KIND, P2, true, false>(cs[0], cs[1], c0);
+        r32_row<KIND, P2, true, true>(cs[r32_first<P2>(1)], cs[r32_first<P2>(1) + 1], c1);
+        r32_row<KIND, P2, true, false>(cn[0], cn[1], c2);
+        r32_row<KIND, P2, true, true>(cn[r32_first<P2>(1)], cn[r32_first<P2>(1) + 1], c3);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            // the last chroma row: r + 1 and r + 2 clamp onto r itself (cn then holds this tile's rows again: c3 == c1)
+            const float in = c1[v] + (below ? c2[v] : c1[v]), outer = c0[v] + (below ? c3[v] : c1[v]);
+            // exact in fp32 (integers below 2^13); >> 4 of a possibly negative sum = floor
+            float f = __builtin_floorf((9.0f * in - outer + 8.0f) * 0.0625f);
+            cf[v] = __builtin_fminf(__builtin_fmaxf(f, 0.0f), 255.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < R32_ROWS; r++) {
+            float yf[8];
+            if (r == 0) r32_row<KIND, P2, false, false>(ys[r32_first<P2>(0)], ys[r32_first<P2>(0) + 1], yf);
+            else if (r == 1) r32_row<KIND, P2, false, true>(ys[r32_first<P2>(1)], ys[r32_first<P2>(1) + 1], yf);
+            else if (r == 2) r32_row<KIND, P2, false, false>(ys[r32_first<P2>(2)], ys[r32_first<P2>(2) + 1], yf);
+            else r32_row<KIND, P2, false, true>(ys[r32_first<P2>(3)], ys[r32_first<P2>(3) + 1], yf);
+            const float *c = r < 2 ? c0 : cf; // U0 V0 U1 V1 U2 V2 U3 V3
+            const r32x4 v = { pack_u8x4(c[0], yf[0], c[1], yf[1]), pack_u8x4(c[2], yf[2], c[3], yf[3]), pack_u8x4(c[4], yf[4], c[5], yf[5]),
+                              pack_u8x4(c[6], yf[6], c[7], yf[7]) };
+            const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+            uint8_t *o = out + 2u * (size_t)pix; // 16 bytes per lane, 1 KiB contiguous per wave
+            if (nt) __builtin_nontemporal_store(v, (r32x4 *)o);
+            else *(r32x4 *)o = v;
+        }
+        return;
+    }
+
     // merged uint8: the lanes of a run (the lanes of a wave that share the output rows) exchange their 24-byte row pieces through LDS
     // so that the run's 24 A contiguous bytes leave as 16-byte stores (cf. MergedRun, vpp_device.h)
     __shared__ __attribute__((aligned(16))) uint8_t slab[OUT == O_U8_MERGED ? MAX_THREADS * 24 : 16];
@@ -194,7 +238,7 @@ template <int KIND, int P2>
 static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
 #define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
-        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8)
+        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8)
 #undef TSVPP_R32
     default: return hipErrorInvalidValue;
     }
