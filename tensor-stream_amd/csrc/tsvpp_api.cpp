@@ -752,10 +752,10 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on) {
     return TSVPP_OK;
 }
 
-// UYVY (uint8) behind a resize: does the streaming kernel take it (exact 3 : 2 or 2 : 1, BILINEAR / AREA / NEAREST, dword-aligned planes,
+// UYVY / YUV444 (uint8) behind a resize: does the streaming kernel take it (exact 3 : 2 or 2 : 1, BILINEAR / AREA / NEAREST, dword-aligned planes,
 // width % 8 == 0, height % 4 == 0, 16-byte aligned outputs)?  Asked of launch_fused itself, as a dry run: one set of conditions.
 static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void *const *outs, hipStream_t stream) {
-    if (pl.fourcc != TSVPP_UYVY || pl.f32 || pl.mode == M_NONE) return false;
+    if ((pl.fourcc != TSVPP_UYVY && pl.fourcc != TSVPP_YUV444) || pl.f32 || pl.mode == M_NONE) return false;
     if (outs)
         for (int f = 0; f < n; f++)
             if (((uintptr_t)outs[f] & 15) != 0) return false;
@@ -763,7 +763,7 @@ static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void 
     dd.n_frames = n < TSVPP_MAX_BATCH ? (n > 0 ? n : 1) : TSVPP_MAX_BATCH;
     FrameTable t = {};
     LaunchInfo info = {};
-    return launch_fused(pl.mode, O_UYVY_U8, true, dd, t, stream, &info) == hipSuccess;
+    return launch_fused(pl.mode, pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8, true, dd, t, stream, &info) == hipSuccess;
 }
 
 int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
@@ -839,7 +839,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // Formats other than RGB24/BGR24: the reference feeds its other colour kernels with
     // the resized NV12; here pass 1 (only if there is a resize) writes that intermediate with the
     // fused kernel, pass 2 converts it.  Crop alone needs no pass 1: it is pointer arithmetic.
-    // ... unless the streaming 3 : 2 / 2 : 1 kernel takes the request: it writes UYVY (uint8) itself, in one pass (vpp_bilinear_r32.hip)
+    // ... unless the streaming 3 : 2 / 2 : 1 kernel takes the request: it writes UYVY / YUV444 (uint8) itself, in one pass (vpp_bilinear_r32.hip)
     const bool single = single_pass_format(pl, d, n, outs, (hipStream_t)stream);
     const bool two_pass = (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && !single;
     uint8_t *scratch = nullptr;
@@ -854,7 +854,7 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         if (sts != TSVPP_OK) return sts;
         scratch = slot->buf;
     }
-    const OutKind out_kind = single ? O_UYVY_U8 : pl.out;
+    const OutKind out_kind = single ? (pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8) : pl.out;
     if (two_pass && d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
         const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
@@ -974,10 +974,10 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
         }
     }
     const bool single = aligned_outputs != 0 && single_pass_format(pl, d, n_frames, nullptr, nullptr);
-    const OutKind out_kind = single ? O_UYVY_U8 : pl.out;
+    const OutKind out_kind = single ? (pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8) : pl.out;
     const bool two_pass = (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && !single;
     d.n_frames = n_frames < TSVPP_MAX_BATCH ? n_frames : TSVPP_MAX_BATCH;
-    static const char *const out_names[O_COUNT_ALL] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32", "uyvy_u8" };
+    static const char *const out_names[O_COUNT_ALL] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32", "uyvy_u8", "yuv444_u8" };
     static const char *const mode_names[M_COUNT] = { "none", "nearest", "bilinear", "bicubic", "area_down", "area_up" };
     LaunchInfo info = {};
     info.kernel = "(none)";

@@ -20,7 +20,8 @@
 // RATIO 4 (template parameter P2 = twice the ratio) is the 2 : 1 case (3840x2160 -> 1920x1080, 1920x1080 -> 960x540) on the same skeleton:
 // 1.5 j + 0.25 becomes 2 j + 0.5 -- taps (2 j, 2 j + 1) with weights (1/2, 1/2) for every index --, a thread's 8 columns are 16 source bytes
 // (dwordx4 loads) and its 4 rows 8 luma / 4 chroma source rows; AREA sums the 2 x 2 box and divides by 4, NEAREST takes tap 2 j.
-// UYVY (uint8) is one more output of the same pass: see the kernel body (the vertical chroma filter needs the tile below's two chroma rows).
+// UYVY and YUV444 (uint8) are two more outputs of the same pass: see the kernel body (the vertical chroma filter needs the tile below's two chroma
+// rows, YUV444's horizontal one the pairs around the thread's four).
 // Outputs: RGB24 / BGR24 uint8 planar (8-byte stores) and merged (24 bytes per lane and row, exchanged through LDS inside the wave so
 // that every store instruction writes a contiguous run), NV12, Y800.  fp32 outputs stay on vpp_bilinear_kernel: it sits on the
 // HBM floor of its write pattern already, and 8 fp32 columns per lane would split every line between two store instructions.
@@ -79,6 +80,86 @@ __device__ __forceinline__ void r32_row(const uint32_t (&top)[P2], const uint32_
         else out[v] = (float)(acc & 255u);
     }
 }
+// YUV444 needs the 4:2:2 chroma of the pair BEFORE the thread's four and of the two pairs AFTER them (its odd pixels filter across pairs): the
+// same evaluation on an extended run -- one dword before the thread's P2, two after -- for pairs -1 .. 5 (14 values U-1 V-1 U0 V0 ... U5 V5).
+template <int KIND, int P2, bool ODD>
+__device__ __forceinline__ void r32_row_cx(const uint32_t (&top)[P2 + 3], const uint32_t (&bot)[P2 + 3], float (&out)[14]) {
+    constexpr int wy0 = r32_wfirst<KIND, P2>(ODD), wy1 = r32_wsecond<KIND, P2>(ODD);
+#pragma unroll
+    for (int v = 0; v < 14; v++) {
+        const int c = (v >> 1) - 1; // pair column relative to the thread's first
+        const int first = P2 == 4 ? 2 * c : 3 * ((c + 2) / 2 - 1) + (c & 1); // r32_first for c >= -1 (no shift of a negative value)
+        const int b0 = 2 * first + (v & 1) + 4;                               // byte in the extended run
+        const int wa = r32_wfirst<KIND, P2>((c & 1) != 0), wb = r32_wsecond<KIND, P2>((c & 1) != 0);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int d = 0; d < P2 + 3; d++) {
+            const uint32_t mt = r32_w(b0, 2, wa * wy0, wb * wy0, d), mb = r32_w(b0, 2, wa * wy1, wb * wy1, d);
+            if (mt != 0u) acc = __builtin_amdgcn_udot4(top[d], mt, acc, false);
+            if (mb != 0u) acc = __builtin_amdgcn_udot4(bot[d], mb, acc, false);
+        }
+        if constexpr (KIND == R32_BILINEAR) out[v] = (float)((acc >> 8) & 255u);
+        else if constexpr (KIND == R32_AREA) out[v] = P2 == 4 ? area_quot(acc, 2, 2, 0.25f) : area_quot(acc, 3, 3, 1.0f / 9.0f);
+        else out[v] = (float)(acc & 255u);
+    }
+}
+// the vertical 4:2:0 -> 4:2:2 filter of an odd chroma row (src/ColorConversion.cu:107-127): exact in fp32, >> 4 of a possibly negative sum = floor
+__device__ __forceinline__ float r32_vfilt(float cm1, float c, float cp1, float cp2) {
+    const float f = __builtin_floorf((9.0f * (c + cp1) - (cm1 + cp2) + 8.0f) * 0.0625f);
+    return __builtin_fminf(__builtin_fmaxf(f, 0.0f), 255.0f);
+}
+// Row ends of YUV444 (one thread per row end): the resized (U, V) of chroma row cr, pair cp straight from the source plane by the same integer
+// weights -- the pair's two taps are four consecutive bytes U V U V of a source row: two aligned dwords, v_alignbyte, one v_dot4 per component and
+// source row -- and the 4:2:2 chroma of a chroma row there.  Rows outside the image read as 0 (the reference's flat indexing runs off its buffer
+// there, src/ColorConversion.cu:131-138).  The plane base and the pitch are multiples of 4 (a condition of this kernel).
+template <int KIND, int P2> __device__ __forceinline__ void r32_pair_uv(const uint8_t *uv, int pitch, int cr, int cp, float &u, float &v) {
+    const int fr = P2 == 4 ? 2 * cr : 3 * (cr >> 1) + (cr & 1), fc = P2 == 4 ? 2 * cp : 3 * (cp >> 1) + (cp & 1);
+    const bool orow = (cr & 1) != 0, ocol = (cp & 1) != 0;
+    constexpr uint32_t xe = (uint32_t)r32_wfirst<KIND, P2>(false) | ((uint32_t)r32_wsecond<KIND, P2>(false) << 16);
+    constexpr uint32_t xo = (uint32_t)r32_wfirst<KIND, P2>(true) | ((uint32_t)r32_wsecond<KIND, P2>(true) << 16);
+    const uint32_t wx = ocol ? xo : xe; // byte weights of U0 . U1 . (V: one byte up)
+    const uint32_t wy0 = (uint32_t)(orow ? r32_wfirst<KIND, P2>(true) : r32_wfirst<KIND, P2>(false));
+    const uint32_t wy1 = (uint32_t)(orow ? r32_wsecond<KIND, P2>(true) : r32_wsecond<KIND, P2>(false));
+    const uint8_t *p = uv + (size_t)fr * (size_t)pitch + (size_t)(2 * fc);
+    const uint32_t sh = (uint32_t)(uintptr_t)p & 3u; // 0 or 2
+    const uint32_t *a = (const uint32_t *)(p - sh);
+    uint32_t top = a[0], bot = 0;
+    if (sh) top = __builtin_amdgcn_alignbyte(a[1], top, sh);
+    if (KIND != R32_NEAREST) {
+        const uint32_t *b = (const uint32_t *)(p - sh + pitch);
+        bot = b[0];
+        if (sh) bot = __builtin_amdgcn_alignbyte(b[1], bot, sh);
+    }
+    uint32_t au = __builtin_amdgcn_udot4(top, wx * wy0, 0u, false), av = __builtin_amdgcn_udot4(top, (wx * wy0) << 8, 0u, false);
+    if (KIND != R32_NEAREST) {
+        au = __builtin_amdgcn_udot4(bot, wx * wy1, au, false);
+        av = __builtin_amdgcn_udot4(bot, (wx * wy1) << 8, av, false);
+    }
+    if constexpr (KIND == R32_BILINEAR) {
+        u = (float)((au >> 8) & 255u);
+        v = (float)((av >> 8) & 255u);
+    } else if constexpr (KIND == R32_AREA) {
+        u = P2 == 4 ? area_quot(au, 2, 2, 0.25f) : area_quot(au, 3, 3, 1.0f / 9.0f);
+        v = P2 == 4 ? area_quot(av, 2, 2, 0.25f) : area_quot(av, 3, 3, 1.0f / 9.0f);
+    } else {
+        u = (float)(au & 255u);
+        v = (float)(av & 255u);
+    }
+}
+// 4:2:2 chroma of CHROMA row cr (= luma rows 2 cr, 2 cr + 1) at pair cp; `rows` = chroma rows of the image; cr outside it: 0
+template <int KIND, int P2> __device__ __forceinline__ void r32_uyvy_uv(const uint8_t *uv, int pitch, int rows, int cr, int cp, float &u, float &v) {
+    u = v = 0.0f;
+    if (cr < 0 || cr >= rows) return;
+    r32_pair_uv<KIND, P2>(uv, pitch, cr, cp, u, v);
+    if (!(cr & 1)) return;
+    const int last = rows - 1;
+    float um, vm, u1, v1, u2, v2;
+    r32_pair_uv<KIND, P2>(uv, pitch, cr - 1, cp, um, vm);
+    r32_pair_uv<KIND, P2>(uv, pitch, min(cr + 1, last), cp, u1, v1);
+    r32_pair_uv<KIND, P2>(uv, pitch, min(cr + 2, last), cp, u2, v2);
+    u = r32_vfilt(um, u, u1, u2);
+    v = r32_vfilt(vm, v, v1, v2);
+}
 template <int P2> __device__ __forceinline__ void r32_load(const uint8_t *p, uint32_t (&dw)[P2]) {
     if constexpr (P2 == 3) {
         const r32x3 v = *(const r32x3 *)p;
@@ -120,6 +201,111 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         for (int r = 0; r < NCR; r++) r32_load<P2>(pc + (size_t)r * (size_t)d.pitch_uv, cs[r]);
     }
 
+    if constexpr (OUT == O_YUV444_U8) {
+        // YUV444 planar (uint8) of the resized frame in the same pass (reference src/ColorConversion.cu:129-173 on the 4:2:2 image above): Y as it is;
+        // U / V of an even pixel = its pair's 4:2:2 chroma, of an odd pixel (9 (p1 + p2) - (p3 + p4) + 8) / 16 (C division, wrapped to a byte) over
+        // the pair, the next, the previous and the next but one IN FLAT ORDER: before a row's first pair comes the previous row's last, after its
+        // last the next row's first two; outside the image 0; the frame's first odd pixel takes p3 = p1, its last two p4 = p2.
+        // The thread evaluates the 4:2:2 chroma of pairs -1 .. 5 around its four from runs extended by one dword before and two after (its neighbours'
+        // loads: cache hits); the thread at a row's start / end takes the wrapped pairs from the source plane directly (r32_uyvy_px).
+        const bool below = i0 + R32_ROWS < d.dst_h;
+        const bool row_start = j0 == 0, row_end = j0 + R32_COLS >= d.dst_w;
+        uint32_t ce[NCR][P2 + 3], cn[NCR][P2 + 3];
+        {
+            const uint8_t *pc = t.uv[id.frame] + (size_t)(RUN * q);
+            const size_t r_this = (size_t)(NCR * n4), r_next = (size_t)(NCR * (n4 + (below ? 1 : 0)));
+#pragma unroll
+            for (int r = 0; r < NCR; r++) {
+                const uint8_t *a = pc + (r_this + r) * (size_t)d.pitch_uv, *b = pc + (r_next + r) * (size_t)d.pitch_uv;
+                ce[r][0] = row_start ? 0u : *(const uint32_t *)(a - 4);
+                cn[r][0] = row_start ? 0u : *(const uint32_t *)(b - 4);
+#pragma unroll
+                for (int k = 0; k < P2; k++) {
+                    ce[r][1 + k] = cs[r][k];
+                    cn[r][1 + k] = *(const uint32_t *)(b + 4 * k);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    ce[r][1 + P2 + k] = row_end ? 0u : *(const uint32_t *)(a + RUN + 4 * k);
+                    cn[r][1 + P2 + k] = row_end ? 0u : *(const uint32_t *)(b + RUN + 4 * k);
+                }
+            }
+        }
+        // the wrapped pairs (their loads are issued here, behind the tile's own: one wait covers both): luma row i0 + r takes pair -1 from row
+        // i0 + r - 1 (chroma rows 2 n4 - 1, 2 n4, 2 n4, 2 n4 + 1) and pairs 4, 5 from row i0 + r + 1 (chroma rows 2 n4, 2 n4 + 1, 2 n4 + 1, 2 n4 + 2)
+        const int crows = d.dst_h >> 1, cpairs = d.dst_w >> 1, cr0 = 2 * n4;
+        float ws[3][2] = {}, we[3][4] = {};
+        if (row_start) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 - 1 + k, cpairs - 1, ws[k][0], ws[k][1]);
+        }
+        if (row_end) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 + k, 0, we[k][0], we[k][1]);
+                r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 + k, 1, we[k][2], we[k][3]);
+            }
+        }
+        float c0[14], c1[14], c2[14], c3[14], cf[14];
+        r32_row_cx<KIND, P2, false>(ce[0], ce[1], c0);
+        r32_row_cx<KIND, P2, true>(ce[r32_first<P2>(1)], ce[r32_first<P2>(1) + 1], c1);
+        r32_row_cx<KIND, P2, false>(cn[0], cn[1], c2);
+        r32_row_cx<KIND, P2, true>(cn[r32_first<P2>(1)], cn[r32_first<P2>(1) + 1], c3);
+#pragma unroll
+        for (int v = 0; v < 14; v++) cf[v] = r32_vfilt(c0[v], c1[v], below ? c2[v] : c1[v], below ? c3[v] : c1[v]);
+        const uint32_t wh = plane;
+        const bool edge = row_start || row_end;
+        uint32_t pu[2] = { 0, 0 }, pv[2] = { 0, 0 };
+#pragma unroll
+        for (int r = 0; r < R32_ROWS; r++) {
+            float yf[8];
+            if (r == 0) r32_row<KIND, P2, false, false>(ys[r32_first<P2>(0)], ys[r32_first<P2>(0) + 1], yf);
+            else if (r == 1) r32_row<KIND, P2, false, true>(ys[r32_first<P2>(1)], ys[r32_first<P2>(1) + 1], yf);
+            else if (r == 2) r32_row<KIND, P2, false, false>(ys[r32_first<P2>(2)], ys[r32_first<P2>(2) + 1], yf);
+            else r32_row<KIND, P2, false, true>(ys[r32_first<P2>(3)], ys[r32_first<P2>(3) + 1], yf);
+            const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
+            // luma rows 2 rc, 2 rc + 1 share their chroma planes -- except in the threads at a row's ends, where the wrapped pairs (and the frame's
+            // first / last odd pixels) differ from row to row
+            if ((r & 1) == 0 || edge) {
+                float ch[14];
+#pragma unroll
+                for (int v = 0; v < 14; v++) ch[v] = r < 2 ? c0[v] : cf[v];
+                if (row_start) {
+                    const int k = r == 0 ? 0 : (r == 3 ? 2 : 1);
+                    ch[0] = ws[k][0];
+                    ch[1] = ws[k][1];
+                }
+                if (row_end) {
+                    const int k = r == 0 ? 0 : (r == 3 ? 2 : 1);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) ch[10 + v] = we[k][v];
+                }
+                float uo[8], vo[8];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t idx1 = pix + 2u * (uint32_t)p + 1u; // flat index of the pair's odd pixel
+                    const bool first = idx1 == 1u, last2 = idx1 + 3u >= wh;
+#pragma unroll
+                    for (int comp = 0; comp < 2; comp++) {
+                        const float p1 = ch[2 * (p + 1) + comp], p2 = ch[2 * (p + 2) + comp];
+                        const float p3 = first ? p1 : ch[2 * p + comp], p4 = last2 ? p2 : ch[2 * (p + 3) + comp];
+                        // (9 (p1 + p2) - (p3 + p4) + 8) / 16 in C: truncation towards zero, then the conversion to uchar wraps
+                        const int quot = (int)__builtin_truncf((9.0f * (p1 + p2) - (p3 + p4) + 8.0f) * 0.0625f);
+                        (comp ? vo : uo)[2 * p] = p1;
+                        (comp ? vo : uo)[2 * p + 1] = (float)(quot & 255);
+                    }
+                }
+                pu[0] = pack_u8x4(uo[0], uo[1], uo[2], uo[3]);
+                pu[1] = pack_u8x4(uo[4], uo[5], uo[6], uo[7]);
+                pv[0] = pack_u8x4(vo[0], vo[1], vo[2], vo[3]);
+                pv[1] = pack_u8x4(vo[4], vo[5], vo[6], vo[7]);
+            }
+            st8(out, pix, pack_u8x4(yf[0], yf[1], yf[2], yf[3]), pack_u8x4(yf[4], yf[5], yf[6], yf[7]), nt);
+            st8(out + wh, pix, pu[0], pu[1], nt);
+            st8(out + 2 * (size_t)wh, pix, pv[0], pv[1], nt);
+        }
+        return;
+    }
     if constexpr (OUT == O_UYVY_U8) {
         // UYVY (4:2:2) of the resized frame in the same pass (reference src/ColorConversion.cu:107-127, 177-209 on the resized NV12): luma rows
         // 2 r, 2 r + 1 take chroma row r as it is when r is even and clamp((9 (c[r] + c[r+1]) - (c[r-1] + c[r+2]) + 8) >> 4) when r is odd (rows
@@ -238,7 +424,7 @@ template <int KIND, int P2>
 static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
 #define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
-        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8)
+        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8) TSVPP_R32(O_YUV444_U8)
 #undef TSVPP_R32
     default: return hipErrorInvalidValue;
     }

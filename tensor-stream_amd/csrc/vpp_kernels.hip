@@ -1348,7 +1348,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
     // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
     // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
-    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8);
+    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8);
     d.r32 = 0;
     if (d.r32_pref && u8_flavour && vec && !d.force_gather && d.in_aligned4 && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
         if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) {
@@ -1411,7 +1411,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         default: return hipErrorInvalidValue;
         }
     };
-    if (out >= O_COUNT) { // flavours of the streaming kernel alone (O_UYVY_U8): the caller falls back to two passes
+    if (out >= O_COUNT) { // flavours of the streaming kernel alone (O_UYVY_U8, O_YUV444_U8): the caller falls back to two passes
         if (!d.r32) return hipErrorNotSupported;
         return launch_bilinear_r32(out, d, t, stream, info);
     }

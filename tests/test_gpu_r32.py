@@ -74,13 +74,16 @@ def test_r32_batches_crops_two_pass_fallbacks(vpp, oracle):
             check(vpp, oracle, yy, uu, 96, (64, 48), planes=0, rt=rt)
 
 
-@pytest.mark.parametrize("src,pitch", [((1920, 1080), 2048), ((3840, 2160), 3840), ((48, 24), 48), ((1944, 1092), 1952), ((456, 66), 460), ((96, 12), 96)])
+@pytest.mark.parametrize("src,pitch", [((1920, 1080), 2048), ((3840, 2160), 3840), ((48, 24), 48), ((1944, 1092), 1952), ((456, 66), 460), ((96, 12), 96),
+                                       ((24, 12), 24), ((48, 48), 64)])   # 8 / 16 output columns: a row's first thread is (next to) its last
 @pytest.mark.parametrize("rt", [BILINEAR, AREA, NEAREST])
 @pytest.mark.parametrize("ratio", [(3, 2), (2, 1)])
-def test_r32_uyvy_in_one_pass(vpp, oracle, src, pitch, rt, ratio):
-    """UYVY (uint8) behind a 3 : 2 / 2 : 1 resize is an output of the streaming kernel itself -- no NV12 intermediate, no second pass: the
+@pytest.mark.parametrize("fmt", [UYVY, YUV444])
+def test_r32_uyvy_yuv444_in_one_pass(vpp, oracle, src, pitch, rt, ratio, fmt):
+    """UYVY / YUV444 (uint8) behind a 3 : 2 / 2 : 1 resize are outputs of the streaming kernel itself -- no NV12 intermediate, no second pass: the
     vertical (-1, 9, 9, -1) chroma filter of the odd chroma rows (clamped at the last row: sizes with one, two and many tile rows), both
-    clamps of the filter (full-range random chroma), every tap kind."""
+    clamps of the filter (full-range random chroma), every tap kind; YUV444's horizontal filter in the reference's FLAT pair order (a row's first
+    pair follows the previous row's last; zeros outside the image; the frame's first and last two odd pixels), its C division and byte wrap."""
     import tensor_stream as ts
     from tensor_stream import vpp as V
     w, h = src
@@ -88,26 +91,28 @@ def test_r32_uyvy_in_one_pass(vpp, oracle, src, pitch, rt, ratio):
     if dst[0] % 8 or dst[1] % 4 or dst[0] * ratio[0] != w * ratio[1] or dst[1] * ratio[0] != h * ratio[1]:
         pytest.skip("not a size of the streaming kernel")
     y, uv = synth_nv12(w, h, seed=w + rt + ratio[0], pitch=pitch)
-    fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=rt, pixel_format=UYVY, planes_pos=1, normalization=False)
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=rt, pixel_format=fmt, planes_pos=1, normalization=False)
     if not any(k.startswith("TSVPP_") for k in os.environ):
         dsc = V.describe(fp, w, h, pitch=pitch)
-        assert dsc["out"] == "uyvy_u8" and dsc["kernel"].startswith("vpp_bilinear_r32_kernel") and "pass2" not in dsc, dsc
-    check(vpp, oracle, y, uv, w, dst, fourcc=UYVY, planes=1, rt=rt)
-    check(vpp, oracle, y, uv, w, dst, fourcc=UYVY, planes=1, rt=rt, n=5)
+        assert dsc["out"] == ("uyvy_u8" if fmt == UYVY else "yuv444_u8") and dsc["kernel"].startswith("vpp_bilinear_r32_kernel") and "pass2" not in dsc, dsc
+    check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt)
+    check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt, n=5)
 
 
 def test_r32_uyvy_fallbacks(vpp, oracle):
-    """Requests next to the single-pass domain keep the two passes: fp32 UYVY, YUV444, a misaligned crop origin, a misaligned output."""
+    """Requests next to the single-pass domain keep the two passes: fp32 UYVY / YUV444, a misaligned crop origin, a misaligned output."""
     import tensor_stream as ts
     from tensor_stream import vpp as V
     y, uv = synth_nv12(1920, 1080, seed=35, pitch=2048)
-    for kw in (dict(pixel_format=UYVY, normalization=True), dict(pixel_format=YUV444, normalization=False), dict(pixel_format=UYVY, normalization=False, crop_coords=(6, 2, 966, 542), width=640, height=360)):
+    for kw in (dict(pixel_format=UYVY, normalization=True), dict(pixel_format=YUV444, normalization=True), dict(pixel_format=UYVY, normalization=False, crop_coords=(6, 2, 966, 542), width=640, height=360)):
         args = dict(width=1280, height=720, resize_type=BILINEAR, planes_pos=1)
         args.update(kw)
         dsc = V.describe(ts.FrameParameters(**args), 1920, 1080, pitch=2048)
         assert dsc["out"] == "nv12_u8" and dsc["pass2"].startswith("fmt_"), dsc
     check(vpp, oracle, y, uv, 1920, (640, 360), fourcc=UYVY, planes=1, crop=(6, 2, 966, 542), r32=False)
     check(vpp, oracle, y, uv, 1920, (640, 360), fourcc=UYVY, planes=1, crop=(4, 2, 964, 542))      # aligned crop: one pass
+    check(vpp, oracle, y, uv, 1920, (640, 360), fourcc=YUV444, planes=1, crop=(4, 2, 964, 542))
+    check(vpp, oracle, y, uv, 1920, (640, 360), fourcc=YUV444, planes=1, crop=(6, 2, 966, 542), r32=False)
     # an output pointer that is not 16-byte aligned: two passes (the element-wise format kernel), same bytes
     fp = ts.FrameParameters(width=1280, height=720, resize_type=BILINEAR, pixel_format=UYVY, planes_pos=1, normalization=False)
     ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
