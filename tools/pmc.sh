@@ -11,6 +11,8 @@ pass sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
 pass lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
 pass tcp "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
 pass sq2 "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAVE_DEP_WAIT SQ_INSTS_WAVE32_VALU"
-{ echo "# $TAG: $ENVS bench.py $@"; for p in sq lds tcp sq2; do python $R/tools/pmc_summary.py $(find $OUT/$p -name "*counter_collection.csv"); done; } > $R/gpurun_out/pmc_$TAG.txt 2>&1
+pass tcc "TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RD_UNCACHED_32B_sum"
+pass tcc2 "TCC_TAG_STALL_sum TCC_EA_RDREQ_DRAM_sum TCC_BUBBLE_sum TCC_READ_sum"
+{ echo "# $TAG: $ENVS bench.py $@"; for p in sq lds tcp sq2 tcc tcc2; do python $R/tools/pmc_summary.py $(find $OUT/$p -name "*counter_collection.csv"); done; } > $R/gpurun_out/pmc_$TAG.txt 2>&1
 find $OUT -type f ! -name "*.log" -delete
 cat $R/gpurun_out/pmc_$TAG.txt
