@@ -129,7 +129,11 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
  * footprints, per-column and per-row coordinates and weights, evaluated once on the host) for the tile shape a batch of
  * `n_frames` frames runs with; a conversion that was not prepared builds them on first use -- except while its stream
  * is being captured into a graph, where it never allocates and runs the kernel that computes coordinates itself (same
- * bits).  tsvpp_prepare == tsvpp_prepare_batch(..., 0, NULL): tables only (single-frame tile shape). */
+ * bits).  The tables are prepared for frames as the decoder delivers them: pitches that are multiples of 16 and plane
+ * pointers that keep the crop origin dword-aligned; a conversion whose real pitches / alignment select another tile shape
+ * builds its own set on first use (or, while capturing, runs the self-computing kernel).  A context keeps the table sets of
+ * its 1024 most recently used geometries.  tsvpp_prepare == tsvpp_prepare_batch(..., 0, NULL): tables only (single-frame
+ * tile shape). */
 int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height);
 int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height, int n_frames, void *stream);
 

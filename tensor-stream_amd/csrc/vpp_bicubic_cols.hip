@@ -448,10 +448,11 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
     std::lock_guard<std::mutex> lk(cache->mu);
     auto it = cache->map.find(key);
     if (it == cache->map.end()) {
-        if (!may_build || cache->map.size() >= 1024) return nullptr;
+        if (!may_build) return nullptr;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
         if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+        geo_cache_make_room(cache);
         std::vector<uint8_t> buf;
         auto append = [&](const void *p, size_t n) {
             const size_t at = buf.size();
@@ -492,6 +493,7 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
         }
         it = cache->map.emplace(key, e).first;
     }
+    it->second.stamp = ++cache->clock;
     return (const BcEntry *)it->second.dev;
 }
 

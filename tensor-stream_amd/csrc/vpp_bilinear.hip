@@ -607,7 +607,6 @@ void geo_cache_destroy(GeoCache *c) {
         if (e.second.dev) (void)hipFree(e.second.dev);
     delete c;
 }
-constexpr size_t kGeoMaxEntries = 256; // beyond that (a context that has seen 256 geometries) new ones keep vpp_bilinear_kernel
 
 // The tables of this launch (d: shape and LDS layout already chosen), built and uploaded on first use.  Never allocates while
 // the stream is being captured into a graph (the launch then keeps vpp_bilinear_kernel; tsvpp_prepare_batch avoids that).
@@ -623,9 +622,11 @@ static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStr
     std::lock_guard<std::mutex> lk(cache->mu);
     auto it = cache->map.find(key);
     if (it == cache->map.end()) {
-        if (!may_build || cache->map.size() >= kGeoMaxEntries) return false;
+        if (!may_build) return false;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
         if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+        geo_cache_make_room(cache);
         GeoHost g;
         GeoEntry e;
         if (geo_tables_host(areaup, d, g)) {
@@ -649,6 +650,7 @@ static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStr
         }
         it = cache->map.emplace(key, e).first;
     }
+    it->second.stamp = ++cache->clock;
     const GeoEntry &e = it->second;
     if (!e.dev) return false;
     out.geo_tx = (const int4 *)e.dev;

@@ -142,11 +142,25 @@ struct GeoKey {
 struct GeoEntry {
     uint8_t *dev = nullptr; // one allocation (null: the request is not eligible)
     size_t off_ty = 0, off_col = 0, off_row = 0;
+    uint64_t stamp = 0;     // last use (GeoCache::clock)
 };
 struct GeoCache {
-    std::mutex mu;
+    std::mutex mu; // held while a missing table set is built and uploaded (~0.1 ms, once per geometry): callers of other geometries wait that long
     std::map<GeoKey, GeoEntry> map;
+    uint64_t clock = 0;
 };
+constexpr size_t kGeoMaxEntries = 1024;
+// With the lock held, before an insertion: a full cache releases its least recently used table set.  hipFree waits for the device, so work that
+// still reads the set has finished by then -- a one-off stall at the 1025th distinct geometry of a context, instead of leaving every later
+// geometry on the slower kernels for good (round 2).  Never reached while the stream is capturing (the lookups return before).
+inline void geo_cache_make_room(GeoCache *c) {
+    if (c->map.size() < kGeoMaxEntries) return;
+    auto victim = c->map.begin();
+    for (auto it = c->map.begin(); it != c->map.end(); ++it)
+        if (it->second.stamp < victim->second.stamp) victim = it;
+    if (victim->second.dev) (void)hipFree(victim->second.dev);
+    c->map.erase(victim);
+}
 GeoCache *geo_cache_create();
 void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has selected the device
 

@@ -161,3 +161,30 @@ def test_batch_of_64_frames_and_consumer_streams(vpp, oracle):
     for i in (0, 1, 31, 63):
         ref = oracle.convert(frames[i][0], frames[i][1], dst=(300, 200), resize_type=BICUBIC, fourcc=2, planes=0, normalization=True, nthreads=4)[0]
         assert np.array_equal(o[i].ravel().view(np.uint8), ref.view(np.uint8))
+
+
+def test_table_cache_evicts_least_recently_used(oracle):
+    """A context keeps the host-built tables of its 1024 most recently used geometries: the 1025th releases the oldest set (round 2
+    stopped caching at 256 and left every later geometry on the slower kernels); an evicted geometry is rebuilt on its next use."""
+    import tensor_stream as ts
+    v = ts.VideoProcessor(device=0)
+    y, uv = synth_nv12(96, 64, seed=77)
+    ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+    sizes = [(40 + 2 * (k % 40), 20 + 2 * (k // 40)) for k in range(1040)]   # 1040 distinct geometries of one source
+    assert len(set(sizes)) == len(sizes)
+    keep = {}
+    for k, dst in enumerate(sizes):
+        fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=BICUBIC, pixel_format=1, planes_pos=1, normalization=False)
+        out = v.Convert(ty, tuv, fp, width=96)
+        if k in (0, 1, 519, 1039):
+            keep[k] = out
+    torch.cuda.synchronize()
+    for k in (0, 1, 519, 1039, 0):   # geometry 0 was evicted meanwhile: converted again at the end
+        dst = sizes[k]
+        fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=BICUBIC, pixel_format=1, planes_pos=1, normalization=False)
+        got = v.Convert(ty, tuv, fp, width=96)
+        torch.cuda.synchronize()
+        ref = oracle.convert(y, uv, dst=dst, resize_type=BICUBIC, fourcc=1, planes=1, normalization=False, nthreads=2, width=96)[0]
+        assert np.array_equal(got.cpu().numpy().ravel(), ref.view(np.uint8).ravel())
+        assert np.array_equal(keep[k].cpu().numpy().ravel(), ref.view(np.uint8).ravel())
+    v.Close()
