@@ -94,7 +94,9 @@ static BcEntry bc_axis(int idx, float ratio, int clamp_limit, int tap_limit) {
     //     sum_k C_k t_k = sum_k m_k x_k - 255 (m_0 + m_3)      -- three v_dot4_u32_u8, the constant is part of the bias
     uint32_t d0 = 0, d1 = 0, d2 = 0;
     int neg = 0;
+    bool exact = true; // every coefficient is a whole number of 2^-22 units (weights that are multiples of 1/16: 1/2, 1/4, 3/8 ...)
     for (int k = 0; k < 4; k++) {
+        if (c[k] * 4194304.0 != __builtin_rint(c[k] * 4194304.0)) exact = false;
         const int C = (int)__builtin_rint(c[k] * 4194304.0);
         const int m = (k == 0 || k == 3) ? -C : C; // >= 0, <= 2^22
         d0 |= (uint32_t)(m & 255) << (8 * k);
@@ -106,6 +108,12 @@ static BcEntry bc_axis(int idx, float ratio, int clamp_limit, int tap_limit) {
     a.l1 = (int)d1;
     a.l2 = (int)d2;
     a.bias = (1 << (BC_SHIFT - 1)) - 255 * neg;
+    // An index with exact coefficients needs no tie test: its integer sum IS 2^22 times the reference's fp64 sum, and (S + 2^21) >> 22 rounds
+    // a tie the way round() does.  That matters because such indices are exactly where ties are COMMON, not rare: at w = 1/2 the sum is a
+    // multiple of 1/32 and one in 32 is a true tie -- at ratio 2 / 3 (720p -> 1080p) a third of all columns and rows, so that nearly every
+    // wave-wide step found a lane inside the tie zone and ran the fp64 path (measured: 2785 VALU instructions per wave against 1650 in the
+    // listing).  Flag: the sign bit of `maxoff`.
+    if (exact) a.maxoff |= (int)0x80000000;
     return a;
 }
 
@@ -139,10 +147,11 @@ __device__ __forceinline__ uint32_t bc_pack4(int s0, int s1, int s2, int s3) {
 }
 // four sums -> four result bytes; the (rare) sums within reach of a tie are redone as the reference does them
 template <bool EXACT>
-__device__ __forceinline__ uint32_t bc_finish4(const int s[4], const uint32_t tp[4], float w0, float w1, float w2, float w3) {
+__device__ __forceinline__ uint32_t bc_finish4(const int s[4], const uint32_t tp[4], float w0, float w1, float w2, float w3, uint32_t exm) {
     uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
     if constexpr (!EXACT) {
-        const uint32_t k0 = bc_tie_key(s[0]), k1 = bc_tie_key(s[1]), k2 = bc_tie_key(s[2]), k3 = bc_tie_key(s[3]);
+        // exm: all ones for a lane whose coefficients are exact (bc_axis): its keys never fall below the threshold
+        const uint32_t k0 = bc_tie_key(s[0]) | exm, k1 = bc_tie_key(s[1]) | exm, k2 = bc_tie_key(s[2]) | exm, k3 = bc_tie_key(s[3]) | exm;
         if (min(min(k0, k1), min(k2, k3)) < BC_TIE_KEY) { // rarely taken
             if (k0 < BC_TIE_KEY) r = (r & 0xffffff00u) | bc_exact(tp[0], w0);
             if (k1 < BC_TIE_KEY) r = (r & 0xffff00ffu) | bc_exact(tp[1], w1) << 8;
@@ -167,7 +176,7 @@ __device__ __forceinline__ uint32_t bc_taps(const uint32_t (&dw)[NDW], uint32_t 
 }
 
 // Row parameters (wave-uniform: scalar loads).  Rows come in blocks of four: 32 ints = [ws x4 | sel x4 | l0 x4 | l1 x4 | l2 x4 |
-// bias x4 | w x4 | pad x4], so that ONE base address serves a whole phase-2 step.  `rb` = the block of the tile's first row.
+// bias x4 | w x4 | exact x4], so that ONE base address serves a whole phase-2 step.  `rb` = the block of the tile's first row.
 __device__ __forceinline__ int bc_row_ws(BcRows rb, int i) { return rb[(i >> 2) * 32 + (i & 3)]; }
 __device__ __forceinline__ uint32_t bc_row_sel(BcRows rb, int i) { return (uint32_t)rb[(i >> 2) * 32 + 4 + (i & 3)]; }
 
@@ -184,6 +193,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
     const int ylo = bc_row_ws(rb, 0), yhi = min(bc_row_ws(rb, nout - 1) + 3, rows_in_plane - 1); // dense: from the first window's start to the last window's end
     const int ng = SPARSE ? nout : ((yhi - ylo + 1 + 3) >> 2);
     const int xb = STEP * ax.ws + comp; // the lane's window start, byte column of the plane
+    const uint32_t exm = (uint32_t)(ax.maxoff >> 31); // all ones: this lane's coefficients are exact (no tie test)
     const uint32_t tapsel = STEP == 1 ? ax.sel : ax.sel + ax.sel;
     // ---- phase 1: H of every needed source row of this lane's column, four rows per dword of the column
     if (dma && (pitch & 15) == 0) {
@@ -248,7 +258,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
             int s[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
-            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
+            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w, exm);
         }
     } else {
         // direct mode (horizontal ratios >= 3.7, or a pitch that is no multiple of 16): every lane loads the NDW dwords around its own
@@ -256,7 +266,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
         // ahead, with unconditional vector loads (a fixed number per group: the compiler's wait counts stay exact); the others load
         // dword by dword and never read past the last needed byte's dword.
         const uint32_t xoff = pm + (uint32_t)xb;
-        const int xneed = STEP * ax.maxoff;
+        const int xneed = STEP * (ax.maxoff & 0x7fffffff);
         const bool aligned = (pitch & 3) == 0; // every row then has the same misalignment: lane offsets and selectors are loop-invariant
         const uint32_t sh_c = xoff & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
         auto group_rows = [&](int g, int (&rr)[4]) {
@@ -298,7 +308,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
             int s[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
-            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w);
+            *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w, exm);
         };
         // leading groups whose rows all lie above the plane's last row
         int ngf;
@@ -341,7 +351,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
     for (int i = 0; i < nout; i += 4) {
         const BcRows blk = rb + (i >> 2) * 32;
         const bc_i4 ws4 = *(BcRows4)(blk), sel4 = *(BcRows4)(blk + 4), a4 = *(BcRows4)(blk + 8), b4 = *(BcRows4)(blk + 12), c4 = *(BcRows4)(blk + 16),
-                    bias4 = *(BcRows4)(blk + 20);
+                    bias4 = *(BcRows4)(blk + 20), ex4 = *(BcRows4)(blk + 28);
         uint32_t tp[4];
         int s[4];
 #pragma unroll
@@ -354,7 +364,9 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
         }
         uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
         if constexpr (!EXACT) {
-            const uint32_t k0 = bc_tie_key(s[0]), k1 = bc_tie_key(s[1]), k2 = bc_tie_key(s[2]), k3 = bc_tie_key(s[3]);
+            // (rows with exact coefficients: mask of ones from the table, see bc_axis)
+            const uint32_t k0 = bc_tie_key(s[0]) | (uint32_t)ex4[0], k1 = bc_tie_key(s[1]) | (uint32_t)ex4[1], k2 = bc_tie_key(s[2]) | (uint32_t)ex4[2],
+                           k3 = bc_tie_key(s[3]) | (uint32_t)ex4[3];
             if (min(min(k0, k1), min(k2, k3)) < BC_TIE_KEY) { // rarely taken
                 // (four scalar dword loads: ROCm 7.2's clang, given ONE dwordx4 load here, used element 0 for all four weights)
                 const BcRows wp = blk + 24;
@@ -474,8 +486,8 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
                 const BcEntry e = bc_axis(i < n ? i : n - 1, d.yr, d.src_h, tap_limit);
                 int wbits;
                 memcpy(&wbits, &e.w, 4);
-                const int v[7] = { e.ws, (int)e.sel, e.l0, e.l1, e.l2, e.bias, wbits };
-                for (int f = 0; f < 7; f++) a[(size_t)(i >> 2) * 32 + 4 * f + (i & 3)] = v[f];
+                const int v[8] = { e.ws, (int)e.sel, e.l0, e.l1, e.l2, e.bias, wbits, e.maxoff >> 31 /* exact: all ones */ };
+                for (int f = 0; f < 8; f++) a[(size_t)(i >> 2) * 32 + 4 * f + (i & 3)] = v[f];
             }
             append(a.data(), a.size() * sizeof(int));
         };
