@@ -10,6 +10,7 @@ tools/profile.sh c5 --workload c5 > /dev/null 2>&1
 tools/profile.sh area --resize AREA > /dev/null 2>&1
 tools/profile.sh bicubic --resize BICUBIC > /dev/null 2>&1
 tools/profile.sh bicubic480 --custom 1080x608:480x360:BICUBIC:RGB24:PLANAR:1 > /dev/null 2>&1
+tools/profile.sh bicubicup --custom 1280x720:1920x1080:BICUBIC:RGB24:PLANAR:1 > /dev/null 2>&1
 tools/profile.sh area224 --custom 1920x1080:224x224:AREA:RGB24:PLANAR:1 > /dev/null 2>&1
 tools/profile.sh uyvy720 --custom 1920x1080:1280x720:BILINEAR:UYVY:MERGED:0 > /dev/null 2>&1
-for t in headline c2 c3 c4 c5 area bicubic bicubic480 area224 uyvy720; do head -3 gpurun_out/prof_$t/kt/kt_kernel_stats.csv | tail -2 | cut -c1-160; done
+for t in headline c2 c3 c4 c5 area bicubic bicubic480 bicubicup area224 uyvy720; do head -3 gpurun_out/prof_$t/kt/kt_kernel_stats.csv | tail -2 | cut -c1-160; done
