@@ -140,21 +140,26 @@ def test_read_many_64_consumers_c5_shape_matches_oracle_and_reports_its_rate(ora
         for k in (0, 1, 31, 63):
             assert np.array_equal(tensors[k].cpu().numpy().ravel().view(np.uint32), ref.view(np.uint32))
         assert all(tensors[k].data_ptr() != tensors[0].data_ptr() for k in range(1, 64))  # every consumer owns its tensor
-        for _ in range(20):
+        # The rate is host-side wall clock through the interpreter: in some processes the first ~100 calls run at a quarter of the steady
+        # rate (the caching allocator settling on its 177 MB batch tensors), and a full Python garbage collection (~40 ms) lands in one
+        # window or another -- 22 runs of the single-window version of this test failed 5 times at 0.22-0.27 with every steady window at
+        # 0.93.  So: a long warm-up, five short windows, the MEDIAN window judged.
+        for _ in range(150):
             r.read_many(names, **C5)
         torch.cuda.synchronize()
-        n = 200
-        t0 = time.perf_counter()
-        for _ in range(n):
-            r.read_many(names, **C5)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        n, dts = 60, []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r.read_many(names, **C5)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
     finally:
         r.stop()
-    fps = 64 * n / dt
-    frac = fps * 15206400 / 8e12
-    print(f"\\nfacade read_many: {fps:.0f} conversions/s, {frac:.3f} of the 8 TB/s roofline (C5 bytes per conversion)")
-    assert frac > 0.30, frac  # (host-side: the Python loop issues ~4-8 k batched launches per second; measured 0.35-0.93 on the pool's boxes)
+    fracs = [64 * n / dt * 15206400 / 8e12 for dt in dts]
+    frac = sorted(fracs)[2]
+    print(f"\\nfacade read_many: {64 * n / sorted(dts)[2]:.0f} conversions/s, median window {frac:.3f} of the 8 TB/s roofline (C5 bytes per conversion); windows {[round(f, 3) for f in fracs]}")
+    assert frac > 0.30, fracs  # one launch per read() reaches ~0.30; measured here: 0.90-0.94
 
 
 def test_64_consumer_threads_coalesce_into_few_launches(oracle):
