@@ -160,3 +160,24 @@ def test_status_codes_match_convert():
     fp = ts.FrameParameters(crop_coords=(100, 0, 2000, 720))  # smaller than the frame in both dimensions, but sticking out of it
     with pytest.raises(RuntimeError, match="-3"):
         ts.describe(fp, 1920, 1080)
+
+
+def test_area_weight_rows_have_unit_interior_taps():
+    """The streaming AREA kernel's lean arithmetic (ratios > 16) skips the multiply of column taps 1 .. 4 * nkx - 5 because they weigh
+    exactly 1.0f in EVERY row of the weight table (the reference's rows are [rest] 1 ... 1 [last fraction], truncated to ceil(ratio)
+    entries); the host checks it per table (AreaTable::ones_end) and this pins the property itself on the table the C ABI exports."""
+    import ctypes
+    import numpy as np
+    from tensor_stream import _native as N
+    lib = N.lib()
+    for num, den in [(3840, 224), (3840, 128), (1920, 224), (1920, 300), (4096, 240), (7680, 300), (3840, 608), (2160, 72), (1920, 104)]:
+        scale = np.float32(num) / np.float32(den)
+        buf = (ctypes.c_float * (1 << 18))()
+        taps = ctypes.c_int(0)
+        rows = lib.tsvpp_area_pattern(ctypes.c_float(float(scale)), buf, len(buf), ctypes.byref(taps))
+        assert rows > 0 and taps.value == int(np.ceil(scale))
+        tab = np.frombuffer(buf, np.float32, rows * taps.value).reshape(rows, taps.value)
+        nkx = (taps.value + 3) // 4
+        assert (tab[:, 1: max(1, 4 * nkx - 4)] == 1.0).all(), (num, den)        # what the kernel relies on
+        assert (tab[:, 1: taps.value - 2] == 1.0).all()                        # what the table actually guarantees: taps 1 .. taps - 3
+        assert (tab >= 0).all() and (tab[:, 0] > 0).all()
