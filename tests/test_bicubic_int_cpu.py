@@ -60,3 +60,34 @@ def test_edge_rule_as_weight_folding():
                 assert np.abs(wg).max() < 32768                       # int16 operands of v_dot2_i32_i16
                 got = int_cubic(wg, row[None, ws:ws + 4])[0]
                 assert got == want, (k, lo, hi)
+
+
+def test_column_kernel_scheme_quantised_sums_tie_zone_and_exact_indices():
+    """The arithmetic claims behind vpp_bicubic_cols.hip, for ANY weight: coefficients quantised to C = rint(c 2^22); the integer sum
+    differs from 2^22 x the fp64 sum by at most 510 units, so outside a zone of 560 units around a rounding tie (S + 2^21) >> 22 IS the
+    reference's value; and an index whose coefficients are exact in 2^-22 units (weights that are multiples of 1/16) needs no zone at
+    all -- including true ties, which are COMMON there (w = 1/2: one sum in 32), the reason such indices are exempt (round 3)."""
+    rng = np.random.default_rng(5)
+    p = rng.integers(0, 256, (300000, 4)).astype(np.int64)
+    p[:8] = [[255, 0, 0, 255], [0, 255, 255, 0], [255, 255, 255, 255], [0, 0, 0, 0], [3, 77, 200, 19], [1, 2, 3, 4], [255, 254, 1, 0], [128, 127, 129, 126]]
+    weights = [np.float32(x) for x in (1 / 6, 5 / 6, 0.5, 0.25, 0.3125, 0.4296875, 0.6889, 0.0123, 0.999, 1 / 3, 0.625)]
+    ties_at_half = 0
+    for w in weights:
+        c = coeffs(np.float64(w))
+        C = np.rint(c * 4194304.0).astype(np.int64)
+        exact = bool(np.all(c * 4194304.0 == np.rint(c * 4194304.0)))
+        assert exact == (float(w) * 16 == np.floor(float(w) * 16)), w       # exact <=> the weight is a multiple of 1/16
+        assert C[0] <= 0 <= C[1] and C[3] <= 0 <= C[2]                      # fixed signs: taps 0 and 3 are applied complemented
+        S = (C[None, :] * p).sum(axis=1)
+        val = np.clip((S + (1 << 21)) >> 22, 0, 255)
+        ref = ref_cubic(c, p.astype(np.float64))
+        exact_scaled = (c[None, :] * p).sum(axis=1) * 4194304.0
+        assert np.abs(S - exact_scaled).max() <= 510                        # the error bound the zone is sized for
+        key = (S + (1 << 21) + 560) % (1 << 22)                             # distance-to-tie key of the kernel (the bias holds the 2^21)
+        in_zone = key < 1120
+        assert np.array_equal(val[~in_zone], ref[~in_zone]), w              # outside the zone the integer value is the reference's
+        if exact:
+            assert np.array_equal(val, ref), w                              # exact coefficients: everywhere, true ties included
+            if float(w) == 0.5:
+                ties_at_half = int(((S + (1 << 21)) % (1 << 22) == 0).sum())
+    assert ties_at_half > p.shape[0] // 64                                  # ~1 in 32 sums at w = 1/2 is a true tie
