@@ -184,3 +184,22 @@ def test_product_fails_loudly_without_the_hip_library_or_a_gpu(monkeypatch):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             ts.VideoProcessor(device=0)
+
+
+def test_cpp_mirror_exports_the_reference_class_and_stage_launchers():
+    """libtsvpp_host.so (tensor-stream_amd/cpp): the reference's public C++ surface for this path -- class VideoProcessor (Init, Convert,
+    DumpFrame, Close; include/VideoProcessor.h:117-147), channelsByFourCC and the three stage launchers (:110-115) -- by their mangled names,
+    with the reference's signatures (hipStream_t in place of cudaStream_t)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tensor-stream_amd", "lib", "libtsvpp_host.so")
+    assert os.path.exists(so), "python -c 'import __graft_entry__ as g; g.build()'"
+    syms = subprocess.run(["nm", "-D", "--defined-only", "-C", so], capture_output=True, text=True, check=True).stdout
+    for needle in ("cropHost(AVFrame*, AVFrame*, CropOptions, int, ihipStream_t**)",
+                   "resizeKernel(AVFrame*, AVFrame*, bool, ResizeOptions, int, ihipStream_t**)",
+                   "int colorConversionKernel<float>(AVFrame*, AVFrame*, ColorOptions, int, ihipStream_t**)",
+                   "int colorConversionKernel<unsigned char>(AVFrame*, AVFrame*, ColorOptions, int, ihipStream_t**)",
+                   "VideoProcessor::Init(", "VideoProcessor::Convert(AVFrame*, AVFrame*, FrameParameters&, std::", "VideoProcessor::DumpFrame<",
+                   "VideoProcessor::Close()", "channelsByFourCC(FourCC)"):
+        assert needle in syms, needle
