@@ -1,5 +1,5 @@
 // Micro-probe (gfx950): rounding of v_cvt_pk_u8_f32 under the default and the round-toward-zero FP mode, and which bits of
-// the shift operand v_alignbyte_b32 uses.   hipcc --offload-arch=gfx950 -O2 -o tools/bin/dbg_cvt tools/dbg_cvt.hip
+// the shift operand v_alignbyte_b32 uses.   hipcc --offload-arch=gfx950 -O2 -o tools/bin/probe_cvt_alignbyte tools/probe_cvt_alignbyte.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
