@@ -147,12 +147,90 @@ def test_stale_traffic_entries_are_dropped(tmp_path):
     assert tr is None and "dispatches" in why
 
 
+def _pmc_csv(path, counter, rows):
+    """A rocprofv3 *_counter_collection.csv reduced to the columns the tools read."""
+    with open(path, "w") as f:
+        f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+        for i, (k, v) in enumerate(rows):
+            f.write(f'{i},"{k}","{counter}",{v}\n')
+
+
+def test_traffic_entry_is_one_kernels_mean_not_a_blend(tmp_path):
+    """round 3's tools averaged every tsvpp:: row; the headline entry was a blend of six kernels.  A CSV with two
+    tsvpp kernels (+ a torch kernel) must reduce to the NAMED kernel's dispatches only."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_lib
+    import traffic_json
+    hk = "void tsvpp::vpp_bilinear_kernel<false, 2>(tsvpp::LaunchDesc, tsvpp::FrameTable)"
+    ok = "void tsvpp::vpp_area_box_kernel<6, true, 2>(tsvpp::LaunchDesc, tsvpp::FrameTable)"
+    tk = "void at::native::vectorized_elementwise_kernel<4>(int)"
+    _pmc_csv(tmp_path / "f.csv", "FETCH_SIZE", [(hk, 97300.0)] * 5 + [(ok, 389000.0)] * 9 + [(tk, 5.0)] * 3 + [(hk, 97302.0)] * 5)
+    _pmc_csv(tmp_path / "w.csv", "WRITE_SIZE", [(hk, 691200.0)] * 10 + [(ok, 172800.0)] * 9 + [(tk, 7.0)] * 3)
+    line = {"roofline": {"kernel": "tsvpp::vpp_bilinear_kernel<bilinear,OUT>", "bytes_per_frame": 14169600, "write_bytes_per_frame": 11059200},
+            "config": {"frames_per_launch": 64.0}}
+    e = traffic_json.entry("rXX", "headline", str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), line, lambda k: "0" * 16)
+    assert e["dispatches"] == 10 and e["kernel_csv_name"] == "tsvpp::vpp_bilinear_kernel<false, 2>"
+    assert e["read_bytes"] == int(2 * 97301.0 * 1024) and e["write_bytes"] == 691200 * 1024
+    assert e["algorithmic_write_bytes_per_launch"] == 11059200 * 64 and e["algorithmic_read_bytes_per_launch"] == 3110400 * 64
+    # without a name: the tsvpp kernel with the most dispatches; a name that was never dispatched: nothing (never a blend)
+    assert pmc_lib.pick_kernel(pmc_lib.load(str(tmp_path / "f.csv"))) == hk
+    assert pmc_lib.pick_kernel(pmc_lib.load(str(tmp_path / "f.csv")), "tsvpp::vpp_color_kernel<OUT>") is None
+    means, name = pmc_lib.kernel_means(pmc_lib.load(str(tmp_path / "w.csv")), "tsvpp::vpp_area_box_kernel<6,1,OUT>")
+    assert name == ok and means["WRITE_SIZE"] == (172800.0, 9)
+    with pytest.raises(SystemExit):
+        traffic_json.entry("rXX", "c2", str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), dict(line, roofline=dict(line["roofline"], kernel="tsvpp::vpp_color_kernel<OUT>")), lambda k: "0")
+
+
+def test_implausible_traffic_entries_are_refused(tmp_path):
+    """bench.py refuses an entry whose read or write side is more than 10 % off the algorithmic split unless touched_bytes explains it."""
+    p = tmp_path / "t.json"
+    base = {"round": "rXX", "kernel_src_sha": bench.kernel_src_hash(), "frames_per_launch": 64.0}
+    alg_r, alg_w = 3110400 * 64, 11059200 * 64
+    blend = dict(base, hbm_bytes_per_launch=911294239, read_bytes=341298378, write_bytes=569995860)  # round 3's published headline entry
+    true = dict(base, hbm_bytes_per_launch=907100000, read_bytes=199270400, write_bytes=707812352, dispatches=659)
+    p.write_text(json.dumps({"headline": blend}))
+    tr, why = bench.lookup_traffic("headline", 64.0, str(p), alg_read=alg_r, alg_write=alg_w)
+    assert tr is None and "implausible" in why
+    p.write_text(json.dumps({"headline": true}))
+    tr, why = bench.lookup_traffic("headline", 64.0, str(p), alg_read=alg_r, alg_write=alg_w)
+    assert tr == 907100000 and "659 dispatches" in why
+    # a sparse sampler (C4): reads far below the ROI bytes are accepted only down to the touched bytes
+    c4 = bench.WORKLOADS["c4"]
+    wr = 1280 * 720 * 3 * 64
+    ar = (bench.algorithmic_bytes(c4[0], c4[1], c4[3], c4[4], c4[8]) - 1280 * 720 * 3) * 64
+    tch = (bench.touched_bytes(c4) - 1280 * 720 * 3) * 64
+    p.write_text(json.dumps({"c4": dict(base, hbm_bytes_per_launch=442481814, read_bytes=442481814 - wr, write_bytes=wr)}))
+    tr, why = bench.lookup_traffic("c4", 64.0, str(p), alg_read=ar, alg_write=wr, touched_read=tch)
+    assert tr == 442481814 and "touched_bytes" in why
+    assert bench.lookup_traffic("c4", 64.0, str(p), alg_read=ar, alg_write=wr)[0] is None           # no explanation given
+    p.write_text(json.dumps({"c4": dict(base, hbm_bytes_per_launch=1, read_bytes=tch // 2, write_bytes=wr)}))
+    assert bench.lookup_traffic("c4", 64.0, str(p), alg_read=ar, alg_write=wr, touched_read=tch)[0] is None  # below what it must touch
+
+
+def test_gpus_8_self_spawn_on_gloo():
+    """The driver's SCALE run is the first time this code meets 8 ranks: rehearse the whole flow at world size 8 on gloo (stub engine):
+    ONE line, n_gpus 8, eight per-rank entries, the 4K workloads in the line, whole-job aggregate."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSVPP_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    assert res["n_gpus"] == 8 and res["value"] > 0 and res["scaling"] == "weak"
+    pr = res["per_rank"]
+    assert len(pr["frames_per_s"]) == 8 and len(pr["host_issue_ms_per_step"]) == 8 and all(x > 0 for x in pr["frames_per_s"])
+    assert abs(res["value"] - 8 * 64 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3
+    ow = res["config"]["other_workloads"]
+    assert set(ow) == {"c4", "c5"} and all(ow[k]["frames_per_s"] > 0 for k in ow)
+    assert "cpu_baseline" not in res
+
+
 def test_torchrun_world1_takes_the_collective_path_on_gloo():
     """`torch.distributed.run --nproc-per-node=1 bench.py`: world size 1 still initialises the process group (the GPU twin of
     this test, tests/test_bench_gpu.py, runs the same on the nccl backend) -- one line, per_rank present."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["TSVPP_BENCH_STUB"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(bench._free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]

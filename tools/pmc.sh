@@ -13,6 +13,7 @@ pass tcp "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTA
 pass sq2 "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAVE_DEP_WAIT SQ_INSTS_WAVE32_VALU"
 pass tcc "TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RD_UNCACHED_32B_sum"
 pass tcc2 "TCC_TAG_STALL_sum TCC_EA_RDREQ_DRAM_sum TCC_BUBBLE_sum TCC_READ_sum"
-{ echo "# $TAG: $ENVS bench.py $@"; for p in sq lds tcp sq2 tcc tcc2; do python $R/tools/pmc_summary.py $(find $OUT/$p -name "*counter_collection.csv"); done; } > $R/gpurun_out/pmc_$TAG.txt 2>&1
+KERNEL=$(grep -h '"metric"' $OUT/sq.log | tail -1 | python -c 'import json,sys; print(json.loads(sys.stdin.read())["roofline"]["kernel"])' 2>/dev/null)
+{ echo "# $TAG: $ENVS bench.py $@ -- dispatches of $KERNEL only"; for p in sq lds tcp sq2 tcc tcc2; do python $R/tools/pmc_summary.py --kernel "$KERNEL" $(find $OUT/$p -name "*counter_collection.csv"); done; } > $R/gpurun_out/pmc_$TAG.txt 2>&1
 find $OUT -type f ! -name "*.log" -delete
 cat $R/gpurun_out/pmc_$TAG.txt
