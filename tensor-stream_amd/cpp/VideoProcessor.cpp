@@ -104,16 +104,19 @@ int cropHost(AVFrame *src, AVFrame *dst, CropOptions crop, int, hipStream_t *str
 
 int resizeKernel(AVFrame *src, AVFrame *dst, bool crop, ResizeOptions resize, int, hipStream_t *stream) {
     if (!src || !dst || !stream) CHECK_STATUS(VREADER_ERROR);
-    uint8_t *old_y = src->data[0], *old_uv = src->data[1]; // (src and dst may be the same AVFrame: VideoProcessor::Convert does that)
-    const tsvpp_nv12 in{ old_y, old_uv, src->linesize[0] ? src->linesize[0] : src->width, src->linesize[1] ? src->linesize[1] : src->width, src->width, src->height };
+    // reference src/Resize.cu:465-471: with crop == true the buffers that `dst` held on entry (cropHost's pair -- Convert passes src == dst) are
+    // freed, then dst->data[0..1] are replaced; src's own buffers are never touched.  Both pairs are captured before anything is overwritten.
+    uint8_t *in_y = src->data[0], *in_uv = src->data[1];
+    uint8_t *dst_old_y = dst->data[0], *dst_old_uv = dst->data[1];
+    const tsvpp_nv12 in{ in_y, in_uv, src->linesize[0] ? src->linesize[0] : src->width, src->linesize[1] ? src->linesize[1] : src->width, src->width, src->height };
     tsvpp_params p{};
     p.dst_width = (int)resize.width;
     p.dst_height = (int)resize.height;
     p.resize_type = (int)resize.type;
     CHECK_STATUS(nv12_stage(in, p, dst, *stream));
-    if (crop) { // the input was cropHost's pair (reference src/Resize.cu:465-468; hipFree waits for the work above)
-        CHECK_STATUS((int)hipFree(old_y));
-        CHECK_STATUS((int)hipFree(old_uv));
+    if (crop) { // (hipFree waits for the work above, which may still read the pair when src == dst)
+        CHECK_STATUS((int)hipFree(dst_old_y));
+        CHECK_STATUS((int)hipFree(dst_old_uv));
     }
     return VREADER_OK;
 }

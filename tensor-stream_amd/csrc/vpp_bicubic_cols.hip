@@ -464,7 +464,7 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
         if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-        geo_cache_make_room(cache);
+        if (!geo_cache_make_room(cache)) return nullptr;
         std::vector<uint8_t> buf;
         auto append = [&](const void *p, size_t n) {
             const size_t at = buf.size();
@@ -503,6 +503,7 @@ const BcEntry *bicubic_cols_tables(const LaunchDesc &d, hipStream_t stream, bool
             (void)hipFree(e.dev);
             return nullptr;
         }
+        e.bytes = buf.size();
         it = cache->map.emplace(key, e).first;
     }
     it->second.stamp = ++cache->clock;

@@ -605,6 +605,7 @@ void geo_cache_destroy(GeoCache *c) {
     if (!c) return;
     for (auto &e : c->map)
         if (e.second.dev) (void)hipFree(e.second.dev);
+    for (uint8_t *p : c->retired) (void)hipFree(p);
     delete c;
 }
 
@@ -626,7 +627,7 @@ static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStr
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         // (the NULL stream is never queried: asking the legacy stream while another stream captures in global mode invalidates that capture)
         if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
-        geo_cache_make_room(cache);
+        if (!geo_cache_make_room(cache)) return false;
         GeoHost g;
         GeoEntry e;
         if (geo_tables_host(areaup, d, g)) {
@@ -647,6 +648,7 @@ static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStr
                 (void)hipFree(e.dev);
                 return false;
             }
+            e.bytes = total;
         }
         it = cache->map.emplace(key, e).first;
     }

@@ -141,6 +141,7 @@ struct GeoKey {
 };
 struct GeoEntry {
     uint8_t *dev = nullptr; // one allocation (null: the request is not eligible)
+    size_t bytes = 0;       // its size
     size_t off_ty = 0, off_col = 0, off_row = 0;
     uint64_t stamp = 0;     // last use (GeoCache::clock)
 };
@@ -148,18 +149,30 @@ struct GeoCache {
     std::mutex mu; // held while a missing table set is built and uploaded (~0.1 ms, once per geometry): callers of other geometries wait that long
     std::map<GeoKey, GeoEntry> map;
     uint64_t clock = 0;
+    // Table sets pushed out of the map.  Their device memory stays VALID until the context is destroyed: a lookup hands out raw device pointers
+    // and the caller launches after the lock is released, a captured hipGraph keeps the pointers it was captured with, and a hipFree issued while
+    // another thread captures in global mode invalidates that capture -- so nothing is ever freed under a live context.
+    std::vector<uint8_t *> retired;
+    size_t retired_bytes = 0;
 };
 constexpr size_t kGeoMaxEntries = 1024;
-// With the lock held, before an insertion: a full cache releases its least recently used table set.  hipFree waits for the device, so work that
-// still reads the set has finished by then -- a one-off stall at the 1025th distinct geometry of a context, instead of leaving every later
-// geometry on the slower kernels for good (round 2).  Never reached while the stream is capturing (the lookups return before).
-inline void geo_cache_make_room(GeoCache *c) {
-    if (c->map.size() < kGeoMaxEntries) return;
+constexpr size_t kGeoMaxRetiredBytes = (size_t)256 << 20;
+// With the lock held, before an insertion.  A full map retires its least recently used table set (the set leaves the map, its memory stays
+// allocated: see GeoCache::retired) so that later geometries still get tables; once the retired sets hold kGeoMaxRetiredBytes the cache stops
+// growing for good and the caller takes the kernels that compute their own coordinates (false).  Table sets are tens of KiB: a context reaches
+// that bound after several thousand distinct geometries.
+inline bool geo_cache_make_room(GeoCache *c) {
+    if (c->map.size() < kGeoMaxEntries) return true;
+    if (c->retired_bytes >= kGeoMaxRetiredBytes) return false;
     auto victim = c->map.begin();
     for (auto it = c->map.begin(); it != c->map.end(); ++it)
         if (it->second.stamp < victim->second.stamp) victim = it;
-    if (victim->second.dev) (void)hipFree(victim->second.dev);
+    if (victim->second.dev) {
+        c->retired.push_back(victim->second.dev);
+        c->retired_bytes += victim->second.bytes;
+    }
     c->map.erase(victim);
+    return true;
 }
 GeoCache *geo_cache_create();
 void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has selected the device

@@ -135,13 +135,6 @@ class FrameRing:
         with self.cv:
             return all(not v for v in self.status.values()) and len(self.status) > 0
 
-    def wait_taken(self, timeout):
-        """Producer side (FAST mode): returns once some consumer has taken the latest frame, or after `timeout` seconds -- a
-        producer without real decoding work must not spin on the interpreter lock the consumers need."""
-        with self.cv:
-            if not self.finished and (not self.status or all(self.status.values())):
-                self.cv.wait(timeout)
-
 
 _NV12_DTYPE = np.dtype([("y", np.uint64), ("uv", np.uint64), ("pitch_y", np.int32), ("pitch_uv", np.int32), ("width", np.int32), ("height", np.int32)])
 assert _NV12_DTYPE.itemsize == ctypes.sizeof(N.NV12)
@@ -174,6 +167,11 @@ class _Coalescer:
         self.requests = 0
 
     def convert(self, key, frame, name, fp):
+        out, slot = self.convert_slot(key, frame, name, fp)
+        return out[slot]
+
+    def convert_slot(self, key, frame, name, fp):
+        """-> (what convert_group returned for the caller's group, the caller's index in it)."""
         with self.cv:
             grp = self.open.get(key)
             leader = grp is None
@@ -184,16 +182,21 @@ class _Coalescer:
             self.requests += 1
             if leader:
                 deadline = time.monotonic() + self.window
-                while len(grp.reqs) < self.max_batch:
+                while not grp.closed:
                     left = deadline - time.monotonic()
                     if left <= 0:
                         break
                     self.cv.wait(left)
-                grp.closed = True
-                del self.open[key]
+                if not grp.closed:  # the window ran out: close under the lock, later arrivals open a new group
+                    grp.closed = True
+                    del self.open[key]
                 self.launches += 1
             elif len(grp.reqs) >= self.max_batch:
-                self.cv.notify_all()  # full: wake the leader early
+                # full: the FOLLOWER that filled it closes it, under the lock -- the leader still has to re-acquire the lock, and until it
+                # did later arrivals would keep appending to a group that is already at max_batch
+                grp.closed = True
+                del self.open[key]
+                self.cv.notify_all()
         if leader:
             try:
                 grp.out = self.convert_group([r[0] for r in grp.reqs], fp)
@@ -204,7 +207,15 @@ class _Coalescer:
             grp.done.wait()
         if grp.error is not None:
             raise grp.error
-        return grp.out[slot]
+        return grp.out, slot
+
+
+class _Converted:
+    """A group's batch tensor + the event recorded behind its launch on the leader's stream."""
+    __slots__ = ("out", "event")
+
+    def __init__(self, out, event):
+        self.out, self.event = out, event
 
 
 class TensorStreamConverter:
@@ -242,7 +253,7 @@ class TensorStreamConverter:
                 if self._markers:
                     self._enable_markers()
                 self._ring = FrameRing(self.buffer_size)
-                self._coalescer = _Coalescer(self._convert_group, self.coalesce_window_us * 1e-6) if self.coalesce_window_us > 0 else None
+                self._coalescer = _Coalescer(self._convert_group_event, self.coalesce_window_us * 1e-6) if self.coalesce_window_us > 0 else None
                 self._desc_cache = {}
                 self._stop.clear()
                 self.fps = self._source.fps_num / self._source.fps_den
@@ -372,7 +383,14 @@ class TensorStreamConverter:
             self._vpp.consumer_stream(name)  # claims the consumer's pool slot (reference: a 6th name on a pool of 5 is an error)
             p = frame_parameters.parameters
             key = (bytes(p), tuple(y.shape), y.stride(0), uv.stride(0))
-            tensor = self._coalescer.convert(key, frame, name, frame_parameters)
+            grp, slot = self._coalescer.convert_slot(key, frame, name, frame_parameters)
+            # The group was converted on the LEADER thread's current stream.  This caller may run under another stream
+            # (`with torch.cuda.stream(s)`): order its stream behind the launch, and tell the allocator that the batch tensor is in
+            # use on it, exactly the contract of the non-coalesced path (Convert(consumer=...) ends with cur.wait_stream) -- ADVICE r03.
+            cur = torch.cuda.current_stream(self.cuda_device)
+            cur.wait_event(grp.event)
+            tensor = grp.out[slot]
+            tensor.record_stream(cur)
         else:
             if ev is not None:
                 torch.cuda.current_stream(self.cuda_device).wait_event(ev)  # (the consumer's pooled stream waits for the current one)
@@ -412,6 +430,13 @@ class TensorStreamConverter:
                                              outs.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), cur.cuda_stream))
         return out
 
+    def _convert_group_event(self, frames, fp):
+        """_convert_group + an event behind the launch: what the coalescer's followers order their own streams after."""
+        out = self._convert_group(frames, fp)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.cuda_device))
+        return _Converted(out, ev)
+
     def read_many(self, names, width=0, height=0, resize_type=ResizeType.NEAREST, crop_coords=(0, 0, 0, 0), pixel_format=FourCC.RGB24,
                   planes_pos=Planes.MERGED, normalization=None, delay=0, return_index=False):
         """read() for several consumer names at once: every consumer takes its next frame (the hand-off semantics of read(), under
@@ -433,15 +458,22 @@ class TensorStreamConverter:
 
     def dump(self, tensor, name="default", width=0, height=0, crop_coords=(0, 0, 0, 0), resize_type=ResizeType.NEAREST,
              pixel_format=FourCC.RGB24, planes_pos=Planes.MERGED, normalization=None):
-        """Appends the tensor's raw elements to <name>.yuv (reference src/Wrappers/WrapperPython.cpp:421-456: the tensor is
-        checked against the size / format arguments, a mismatch is an error)."""
-        if width or height:
-            fp = FrameParameters(width=width, height=height, crop_coords=crop_coords, resize_type=resize_type, pixel_format=pixel_format,
-                                 planes_pos=planes_pos, normalization=normalization)
-            from .vpp import output_shape
-            want = output_shape(fp.parameters, int(width), int(height))
-            if tuple(tensor.shape) != tuple(want):
-                raise RuntimeError(f"-3: tensor shape {tuple(tensor.shape)} does not match the dump parameters {tuple(want)}")
+        """Appends the tensor's raw elements to <name>.yuv (reference src/Wrappers/WrapperPython.cpp:421-456).  Like the reference, a width or
+        height of 0 is filled in from the tensor ((H, W, C) for the three-channel formats, (1, H * channels, W) otherwise) and the element
+        count written is that of width x height x channels; unlike the reference (which would read past a smaller tensor) a tensor that does
+        not hold that many elements is an error."""
+        fp = FrameParameters(width=width, height=height, crop_coords=crop_coords, resize_type=resize_type, pixel_format=pixel_format,
+                             planes_pos=planes_pos, normalization=normalization)
+        ch = N.lib().tsvpp_channels(fp.parameters.fourcc)
+        three = ch == 3
+        # (3, H, W) of planar RGB24 / BGR24: the reference reads size(1) / size(0) here as well and dumps 3 x H elements -- not copied
+        planar3 = three and fp.parameters.planes == Planes.PLANAR.value and fp.parameters.fourcc in (FourCC.RGB24.value, FourCC.BGR24.value)
+        if not width:
+            width = tensor.shape[2] if (planar3 or not three) else tensor.shape[1]
+        if not height:
+            height = tensor.shape[1] if planar3 else (tensor.shape[0] if three else int(tensor.shape[1] / ch))
+        if tensor.numel() != int(int(width) * int(height) * ch):
+            raise RuntimeError(f"-3: tensor of {tensor.numel()} elements does not match the dump parameters {width}x{height}x{ch}")
         torch.cuda.synchronize(tensor.device)  # conversions run asynchronously on the consumer's stream
         with open(name + ".yuv", "ab+") as f:
             f.write(tensor.contiguous().cpu().numpy().tobytes())

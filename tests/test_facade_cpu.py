@@ -155,6 +155,16 @@ def test_coalescer_groups_concurrent_requests_and_returns_each_its_slice():
         assert res[i] == ("out", ("frame", i), "fp%d" % (i % 2))   # every caller got ITS frame converted with ITS parameters
     assert sum(calls) == 32 and len(calls) <= 6 and max(calls) <= 16  # two keys x 16 = full groups wake the leader early
     assert co.requests == 32 and co.launches == len(calls)
+    # a full group is closed by the follower that filled it: no group ever exceeds max_batch, whatever the scheduling
+    sizes = []
+    co3 = _Coalescer(lambda frames, fp: (sizes.append(len(frames)), time.sleep(0.001), list(frames))[2], window=0.2, max_batch=4)
+    got = {}
+    th = [threading.Thread(target=lambda i=i: got.__setitem__(i, co3.convert("k", i, f"c{i}", None))) for i in range(203)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=20)
+    assert got == {i: i for i in range(203)} and sum(sizes) == 203 and max(sizes) <= 4 and co3.launches == len(sizes)
     # an error in the batched conversion reaches every member of the group
     co2 = _Coalescer(lambda frames, fp: (_ for _ in ()).throw(RuntimeError("boom")), window=0.02)
     out = []

@@ -232,3 +232,70 @@ def test_raw_nv12_file_source_streams_through_pinned_staging(tmp_path, oracle):
         assert "Decoding finished" in str(e)
     r.stop()
     assert seen == n
+
+
+def test_coalesced_reads_on_the_callers_own_streams(oracle):
+    """with coalesce_window_us the group is converted on the LEADER's stream; a consumer thread that runs under its own
+    torch stream must still see a finished tensor (its stream waits for the group's event) and reads it on that stream right away."""
+    import tensor_stream as ts
+    from tensor_stream.sources import open_source
+    url = "synthetic://3840x2160?seed=9&frames=0&fps=400&pool=2"
+    r = make(url, max_consumers=16, coalesce_window_us=3000)
+    pool = open_source(url).pool
+    r.start()
+    results, errs = {}, []
+
+    def work(name):
+        try:
+            s = torch.cuda.Stream()
+            out = []
+            with torch.cuda.stream(s):
+                for _ in range(5):
+                    t, idx = r.read(name=name, width=1920, height=1080, resize_type=ts.ResizeType.BICUBIC, pixel_format=ts.FourCC.BGR24, planes_pos=ts.Planes.MERGED,
+                                    return_index=True)
+                    out.append((t.clone(), idx))  # consumed on the caller's stream at once, no synchronisation of the caller's own
+            s.synchronize()
+            results[name] = out
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(f"c{i}",)) for i in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    r.stop()
+    assert not errs and len(results) == 16
+    refs = {}
+    for name, out in results.items():
+        for t, idx in out:
+            k = (idx - 1) % 2
+            if k not in refs:
+                refs[k] = oracle.convert(pool[k][0], pool[k][1], dst=(1920, 1080), resize_type=2, fourcc=2, planes=1, normalization=False, nthreads=8)[0]
+            assert np.array_equal(t.cpu().numpy().ravel(), refs[k]), (name, idx)
+
+
+def test_dump_fills_a_missing_dimension_from_the_tensor(tmp_path):
+    """reference WrapperPython.cpp:425-445: width / height of 0 are taken from the tensor, one given dimension is not an error."""
+    import tensor_stream as ts
+    r = make()
+    r.start()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        t = r.read(width=640, height=360, resize_type=ts.ResizeType.BILINEAR)
+        r.dump(t, name="a", width=640)
+        r.dump(t, name="a", height=360)
+        r.dump(t, name="a", width=640, height=360)
+        assert os.stat("a.yuv").st_size == 3 * 640 * 360 * 3
+        p = r.read(width=640, height=360, resize_type=ts.ResizeType.BILINEAR, planes_pos=ts.Planes.PLANAR, normalization=True)
+        r.dump(p, name="p", planes_pos=ts.Planes.PLANAR, normalization=True)
+        assert os.stat("p.yuv").st_size == 640 * 360 * 3 * 4
+        y = r.read(pixel_format=ts.FourCC.NV12)
+        r.dump(y, name="y", pixel_format=ts.FourCC.NV12, width=1920)
+        assert os.stat("y.yuv").st_size == 1920 * 1080 * 3 // 2
+        with pytest.raises(RuntimeError, match="-3"):
+            r.dump(t, name="bad", width=320, height=360)
+    finally:
+        os.chdir(cwd)
+        r.stop()
