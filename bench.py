@@ -726,8 +726,15 @@ def run(args):
     def side(sp, steps=20, wl_name=None):
         try:
             w = eng.side_work(sp)
-            for i in range(3):
-                w.issue(i, eng.cur_stream)
+            # the device idles while rank 0 runs the oracle of the previous leg's parity check: each side leg starts with its own time-based
+            # warm-up (the clock ramp, see --warmup-ms), or its 20 steps would sit on the ramp (first run of round 4: BICUBIC 0.54 instead of 0.63)
+            t_w = time.perf_counter()
+            k = 0
+            while k < 3 or (args.warmup_ms > 0 and (time.perf_counter() - t_w) * 1e3 < args.warmup_ms and k < 100000):
+                for _ in range(4):
+                    w.issue(k, eng.cur_stream)
+                    k += 1
+                eng.sync()
             (sw, sdev, _), _ = region(steps, 0, w)
             bpf = bytes_of(sp)
             ms = sdev / (steps * w.launches_per_step)

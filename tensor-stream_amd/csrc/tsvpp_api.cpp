@@ -213,7 +213,7 @@ struct tsvpp_ctx {
     // (measured after its VGPR fix: 2x 501 k vs 368 k fps, 3x 743 k vs 621 k, 4x 162 k vs 251 k)
     float area_direct_min = 3.5f;   // TSVPP_AREA_DIRECT_MIN
     float area_direct_fmin = 2.0f;  // the same for non-dyadic weights (a constant since round 3)
-    int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernel for dyadic weights
+    int bicubic_int = 1;            // TSVPP_BICUBIC_INT: integer kernels for dyadic weights (1: + the streaming kernel at 3 : 2 / 2 : 1, 2: the LDS kernel only, 0: none)
     int bilinear_int = 1;           // TSVPP_BILINEAR_INT: integer thread tile of the 2x2-tap kernel for dyadic weights
     int area_box = 1;               // TSVPP_AREA_BOX: contiguous-run box kernel for integer ratios >= 4
     int area2 = 1;                  // float-weight AREA at 2 x 2 .. 3 x 3 taps on its own LDS kernel

@@ -130,7 +130,7 @@ struct LaunchDesc {
     // allowed (TSVPP_AREA_STREAM) / chosen by launch_fused; as_nk: its instantiated tap count / 4 (>= nkx); as_rows / as_min_taps: its tile height (4) and
     // cross-over (40 taps per value), constants since the A/B runs of round 3.  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
     int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_ones_x, as_two; // as_ones_x: column taps 1 .. as_ones_x - 1 weigh 1.0f in every table row; as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
-    int r32_pref, r32; // streaming 3 : 2 BILINEAR kernel for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (vpp_bilinear_r32.hip)
+    int r32_pref, r32; // streaming 3 : 2 / 2 : 1 kernels: BILINEAR / AREA / NEAREST for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (1..6: vpp_bilinear_r32.hip; 7, 8: BICUBIC, vpp_bicubic_r32.hip)
     GeoCache *geo_cache;
 };
 
@@ -216,6 +216,9 @@ hipError_t launch_area_stream(OutKind out, const LaunchDesc &d, const FrameTable
 
 // AREA down-scale at integer horizontal ratios 4..8 from contiguous dword runs (vpp_area_box.hip).
 hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
+
+// BICUBIC at exactly 3 : 2 / 2 : 1 on both axes, every output flavour, straight from global memory (vpp_bicubic_r32.hip; d.r32 = 7 / 8).
+hipError_t launch_bicubic_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // BILINEAR at exactly 3 : 2 on both axes, uint8 outputs, straight from global memory (vpp_bilinear_r32.hip).
 hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);

@@ -936,6 +936,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, d, t, grid.x, lds_bytes, stream, info);
         }
     } else if constexpr (MODE == M_BICUBIC) {
+        if (d.r32 >= 7) return launch_bicubic_r32((OutKind)OUT, d, t, stream, info);
         if (d.bicubic_cols) return launch_bicubic_cols((OutKind)OUT, d.bicubic_cols == 2, d, t, lds_bytes, stream, info);
         if (staged && d.bicubic_int) return launch_bicubic_int((OutKind)OUT, d, t, lds_bytes, stream, info);
     } else if constexpr (MODE != M_NONE) {
@@ -1178,7 +1179,15 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip, below)
-    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f;
+    // BICUBIC at exactly 3 : 2 or 2 : 1 on both axes: the streaming kernel of vpp_bicubic_r32.hip (byte coefficients, v_dot4 on the source dwords, no
+    // LDS staging) takes every output flavour (7 / 8 = d.r32 below; TSVPP_BICUBIC_INT=2 keeps the LDS integer kernel)
+    int bc_r32 = 0;
+    if (mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref == 1 && d.bicubic_cols_pref != 2 && vec && !d.force_gather && d.in_aligned4 && out < O_COUNT &&
+        (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
+        if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) bc_r32 = 7;
+        else if (d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) bc_r32 = 8;
+    }
+    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
     if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
         const int want_dma = d.dma;
@@ -1293,7 +1302,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // BICUBIC that the integer kernel above did not take (non-dyadic weights -- or TSVPP_BICUBIC_COLS=2: every request): one wave per
     // 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane (vpp_bicubic_cols.hip).  A taller
     // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
-    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref) {
+    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && !bc_r32) {
         const bool sparse = d.yr >= 4.0f;
         const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
         // LDS-DMA ring: a row segment is (64 columns at ratio xr + window + a misalignment of up to 15 bytes) rounded up to 16-byte chunks,
@@ -1363,6 +1372,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             else if (mode == M_NEAREST) d.r32 = 6;
         }
     }
+    if (bc_r32) d.r32 = bc_r32;
     if (d.r32) {
         d.point_kind = PK_NONE;
         d.area_direct = 0;
@@ -1374,6 +1384,18 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         if (!(d.shape_tx > 0 && d.shape_ty > 0)) { // measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16
             d.tx = 64;
             d.ty = 4;
+            if (d.r32 >= 7) {
+                // The BICUBIC kernel is VALU-bound (uint8: 77 % busy, profiles/r04_bicubic_r32_pmc.txt), so lanes past the right edge cost what they
+                // idle: 1280 columns = 160 threads = 2.5 rows of 64 -- 32-wide workgroups +9 % there; 1920 and 960 columns (240 / 120 threads) lose
+                // 6.7 % of a 64-wide row and still prefer it (longer store runs).  fp32 outputs are bound by the write pattern and want SHORT
+                // tiles, as the 2x2-tap kernel does: two thread rows (profiles/r04_bicubic_r32_shapes.txt).
+                const int n = d.dst_w / 8;
+                auto waste = [&](int tx) { return (double)((n + tx - 1) / tx * tx) / (double)n - 1.0; };
+                // fp32 outputs are bound by the issue of memory instructions, not by the VALU: always 64 wide (neighbour dwords by wave shuffle)
+                d.tx = (f32_out || waste(64) <= 0.08) ? 64 : (waste(32) <= 0.08 ? 32 : (waste(16) < waste(32) ? 16 : 32));
+                d.ty = f32_out ? (out == O_HSV_F32 ? 4 : 2) : 256 / d.tx; // (HSV: three divisions per pixel, VALU-bound again -- 0.60 with four thread rows, 0.53 with two)
+                if (d.ty > 8) d.ty = 8;
+            }
         }
     }
     d.tx_shift = slot_shift_for(d.tx);

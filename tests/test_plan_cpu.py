@@ -42,7 +42,20 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     assert plan((3840, 2160), (1920, 1080), B, norm=False)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"
     assert plan((1920, 1080), (960, 540), B, norm=False)["kernel"] == "vpp_bilinear_r32_kernel<OUT,bilinear,2:1>"
     assert plan((3840, 2160), (1920, 1080), B)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"
-    assert plan((1920, 1080), (1280, 720), C, norm=False)["kernel"] == "vpp_bicubic_int_kernel<OUT>"
+    # BICUBIC at those two ratios (round 4): its own streaming kernel, every output flavour (fp32 too); other dyadic ratios keep the LDS integer kernel
+    for norm, planes in ((False, 0), (True, 0), (False, 1), (True, 1)):
+        p = plan((1920, 1080), (1280, 720), C, norm=norm, planes=planes, pitch=2048)
+        # 1280 columns = 160 threads per row: for uint8 outputs (VALU-bound) 32-wide workgroups leave no lane idle (64-wide: 20 %); fp32 outputs (bound by
+        # the issue of memory instructions): 64 wide -- neighbour dwords by wave shuffle instead of loads --, two thread rows (short tiles)
+        assert (p["kernel"], p["shape"], p["tiles"]) == ("vpp_bicubic_r32_kernel<OUT,3:2>", "64x2" if norm else "32x8", "3x90" if norm else "5x23")
+        assert plan((3840, 2160), (1920, 1080), C, norm=norm, planes=planes)["kernel"] == "vpp_bicubic_r32_kernel<OUT,2:1>"
+    assert plan((1920, 1080), (1280, 720), C, fourcc=HSV)["kernel"] == "vpp_bicubic_r32_kernel<OUT,3:2>"
+    assert plan((1920, 1080), (1536, 864), C)["kernel"] == "vpp_bicubic_int_kernel<OUT>"                                  # 5 : 4
+    assert plan((1920, 1080), (1280, 720), C, pitch=1922)["kernel"] == "vpp_bicubic_int_kernel<OUT>"                      # planes not dword-aligned
+    assert plan((1932, 1080), (1288, 720), C)["kernel"] == "vpp_bicubic_r32_kernel<OUT,3:2>"                              # width 8 k
+    assert plan((1926, 1080), (1284, 720), C)["kernel"] == "vpp_bicubic_int_kernel<OUT>"                                  # width 8 k + 4
+    assert plan((1920, 1086), (1280, 724), C)["kernel"] == "vpp_bicubic_r32_kernel<OUT,3:2>"                              # height 4 k
+    assert plan((1920, 1084), (960, 542), C)["kernel"] == "vpp_bicubic_int_kernel<OUT>"                                   # 2 : 1, height 4 k + 2
     assert plan((1920, 1080), (1280, 720), B, norm=False, pitch=1922)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"   # planes not dword-aligned
     assert plan((1926, 1080), (1284, 720), B, norm=False)["kernel"] == "vpp_bilinear_kernel<bilinear,OUT>"               # width 8 k + 4
     p = plan((1920, 1080), (1366, 768), B, norm=False)                  # float weights: the tables were measured to lose
@@ -72,8 +85,9 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (96, 54), A, "vpp_fused_gather_kernel"),              # 40 x 40: beyond 32 taps
     ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6 = 28 taps: below the streaming kernel's cross-over -> one output column per lane, taps from global memory
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
-    ((1920, 1080), (1280, 720), C, "vpp_bicubic_int_kernel"),           # 1.5: weights in quarters -> integer kernel
-    ((3840, 2160), (1920, 1080), C, "vpp_bicubic_int_kernel"),          # 2: halves
+    ((1920, 1080), (1280, 720), C, "vpp_bicubic_r32_kernel<OUT,3:2>"),  # 1.5: the streaming kernel (round 4)
+    ((3840, 2160), (1920, 1080), C, "vpp_bicubic_r32_kernel<OUT,2:1>"), # 2
+    ((1280, 720), (512, 288), C, "vpp_bicubic_int_kernel"),             # 2.5: weights in quarters -> the LDS integer kernel
     ((960, 540), (1920, 1080), C, "vpp_bicubic_int_kernel"),            # 0.5
     ((1280, 720), (1920, 1080), C, "vpp_bicubic_cols_kernel<OUT,tie,dense>"),   # 2/3: not dyadic -> wave-per-tile kernel with the tie test
     ((1080, 608), (480, 360), C, "vpp_bicubic_cols_kernel<OUT,tie,dense>"),
