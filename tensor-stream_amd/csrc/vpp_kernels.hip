@@ -1384,6 +1384,15 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         if (!(d.shape_tx > 0 && d.shape_ty > 0)) { // measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16
             d.tx = 64;
             d.ty = 4;
+            if (d.r32 < 7 && out == O_YUV444_U8) {
+                // the one VALU-bound flavour of the 2x2-tap streaming kernel (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280
+                // columns = 2.5 rows of 64 threads: 0.465 -> 0.567 on 32 x 4 (profiles/r04_r32_shape_1280.txt); the other flavours do not care
+                const int n = d.dst_w / 8;
+                if ((double)((n + 63) / 64 * 64) / (double)n > 1.08 && (double)((n + 31) / 32 * 32) / (double)n <= 1.08) {
+                    d.tx = 32;
+                    d.ty = 4;
+                }
+            }
             if (d.r32 >= 7) {
                 // The BICUBIC kernel is VALU-bound (uint8: 77 % busy, profiles/r04_bicubic_r32_pmc.txt), so lanes past the right edge cost what they
                 // idle: 1280 columns = 160 threads = 2.5 rows of 64 -- 32-wide workgroups +9 % there; 1920 and 960 columns (240 / 120 threads) lose
