@@ -846,6 +846,43 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_point_kernel(const LaunchDesc
     color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
 }
 
+// No resize, uint8 Y800 / NV12 outputs: the output IS the (cropped) source planes made tight (reference src/ColorConversion.cu:95-105, 211-233) -- a
+// strided copy.  The colour-only kernel below moves it 4 bytes per lane and instruction and reached 0.53 of the roofline (Y800, r03_output_matrix.txt):
+// memory instructions cost the texture addresser per LANE, not per byte (profiles/r04_bicubic_r32_pmc.txt), so the copy takes 16 bytes per lane and
+// four rows per thread (all loads first): thread tile = 16 columns x 4 rows (+ 2 chroma rows), workgroup tile = (16 tx) x (4 ty).
+typedef uint32_t cp_x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t cp_x4a __attribute__((ext_vector_type(4)));
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_copy16_kernel(const LaunchDesc d, const FrameTable t) {
+    const TileId id = decode_tile(d);
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int j0 = (id.tx * d.tx + lx) * 16, i0 = (id.ty * d.ty + ly) * 4;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    const uint8_t *py = t.y[id.frame] + (size_t)i0 * (size_t)d.pitch_y + (size_t)j0;
+    cp_x4 y[4], c[2];
+#pragma unroll
+    for (int r = 0; r < 4; r++) y[r] = *(const cp_x4 *)(py + (size_t)r * (size_t)d.pitch_y);
+    if constexpr (OUT == O_NV12_U8) {
+        const uint8_t *pc = t.uv[id.frame] + (size_t)(i0 >> 1) * (size_t)d.pitch_uv + (size_t)j0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) c[r] = *(const cp_x4 *)(pc + (size_t)r * (size_t)d.pitch_uv);
+    }
+    uint8_t *out = (uint8_t *)t.out[id.frame];
+    const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
+    auto st = [&](uint32_t off, const cp_x4 &v) {
+        const cp_x4a a = { v.x, v.y, v.z, v.w };
+        if (d.nt_stores) __builtin_nontemporal_store(a, (cp_x4a *)(out + off));
+        else *(cp_x4a *)(out + off) = a;
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++) st((uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0, y[r]);
+    if constexpr (OUT == O_NV12_U8) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) st(plane + (uint32_t)((i0 >> 1) + r) * (uint32_t)d.dst_w + (uint32_t)j0, c[r]);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Colour-only kernel (no resize; crop is already folded into the pointers): thread = 2 rows x 4
 // pixels, 4-byte coalesced luma loads, one 4-byte chroma load (2 pairs) shared by the two rows.
@@ -989,6 +1026,12 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             }
         }
     } else {
+        if constexpr (OUT == O_Y800_U8 || OUT == O_NV12_U8) {
+            if (staged && d.copy16) {
+                TSVPP_LAUNCH("vpp_copy16_kernel<OUT>", (vpp_copy16_kernel<OUT>), grid, block, 0);
+                return info ? hipSuccess : hipGetLastError();
+            }
+        }
         if (staged) { // colour-only fast path ("staged" = eligible)
             TSVPP_LAUNCH("vpp_color_kernel<OUT>", (vpp_color_kernel<OUT>), grid, block, 0);
             return info ? hipSuccess : hipGetLastError();
@@ -1354,6 +1397,12 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     }
     const size_t bc_lds = lds_bytes;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
+    // ... and for the outputs that are the planes themselves (uint8 Y800 / NV12) a copy of 16 bytes per lane (vpp_copy16_kernel)
+    d.copy16 = (mode == M_NONE && staged && (out == O_Y800_U8 || out == O_NV12_U8) && (d.dst_w & 15) == 0 && (d.dst_h & 3) == 0) ? 1 : 0;
+    if (d.copy16 && !(d.shape_tx > 0 && d.shape_ty > 0)) {
+        d.tx = 64;
+        d.ty = 4;
+    }
     // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
     // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
     // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
@@ -1412,8 +1461,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (d.bicubic_cols) lds_bytes = bc_lds;
     if (d.r32) d.area_stream = 0;
     if (d.area_stream) lds_bytes = as_lds;
-    const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
-    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : d.r32 ? d.ty * 4 : d.ty * PXH * d.rpt;
+    const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.copy16 ? 16 : d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
+    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : (d.r32 || d.copy16) ? d.ty * 4 : d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;

@@ -148,3 +148,30 @@ def test_row_pair_kernels_fuzz(vpp, oracle, chunk):
         assert got.dtype == ref.dtype and got.size == ref.size
         bad = np.flatnonzero(got.view(np.uint8) != ref.view(np.uint8))
         assert bad.size == 0, ((w, h, pitch, fcc, norm, dst, rt), bad[:8], bad.size)
+
+
+@pytest.mark.parametrize("fcc", [Y800, NV12])
+def test_plane_copies_16_bytes_per_lane(vpp, oracle, fcc):
+    """No resize, uint8 Y800 / NV12: the output is the (cropped) planes made tight -- vpp_copy16_kernel where widths are multiples of 16 and heights of 4,
+    the colour-only kernel elsewhere; both against the oracle, with ragged pitches, crops that keep the planes dword-aligned and batches."""
+    import tensor_stream as ts
+    for (w, h, pitch), crop in [((1920, 1080, 2048), (0, 0, 0, 0)), ((1920, 1080, 1924), (0, 0, 0, 0)), ((1920, 1080, 2048), (64, 32, 1344, 752)),
+                                ((1920, 1080, 2048), (4, 2, 1028, 770)), ((1936, 1088, 1936), (0, 0, 0, 0)), ((1920, 1080, 2048), (8, 8, 1000, 500)),
+                                ((64, 8, 64), (0, 0, 0, 0)), ((16, 4, 20), (0, 0, 0, 0)), ((1920, 1082, 1920), (0, 0, 0, 0))]:
+        y, uv = synth_nv12(w, h, seed=w + h + fcc, pitch=pitch)
+        fp = ts.FrameParameters(crop_coords=crop, pixel_format=fcc, normalization=False)
+        cw, ch = (crop[2] - crop[0], crop[3] - crop[1]) if crop[2] else (w, h)
+        want16 = cw % 16 == 0 and ch % 4 == 0 and pitch % 4 == 0 and crop[0] % 4 == 0
+        k = ts.describe(fp, w, h, pitch=pitch, n_frames=1)["kernel"]
+        assert k.startswith("vpp_copy16_kernel") == want16, (k, w, h, pitch, crop)
+        got = run(vpp, y, uv, fcc, False, crop=crop, width=w)
+        ref, ow, oh = oracle.convert(y, uv, crop=crop, fourcc=fcc, normalization=False, nthreads=8, width=w)
+        assert got.shape == oracle.shape_for(fcc, 1, ow, oh) and np.array_equal(got.ravel(), ref), (w, h, pitch, crop)
+    ys = torch.randint(0, 256, (70, 360, 640), dtype=torch.uint8, device="cuda")
+    uvs = torch.randint(0, 256, (70, 180, 640), dtype=torch.uint8, device="cuda")
+    fp = ts.FrameParameters(pixel_format=fcc, normalization=False)
+    out = vpp.convert_batch(ys, uvs, fp)
+    torch.cuda.synchronize()
+    for i in (0, 63, 64, 69):
+        ref, _, _ = oracle.convert(ys[i].cpu().numpy(), uvs[i].cpu().numpy(), fourcc=fcc, normalization=False)
+        assert np.array_equal(out[i].cpu().numpy().ravel(), ref), i
