@@ -182,27 +182,36 @@ def cpu_baseline(spec, budget_s=12.0, tight_pitch=False):
             "swscale": "unavailable in image"}
 
 
-def facade_leg(dev, n_consumers=64, calls=60, windows=5, warm=150):
+def facade_leg(dev, n_consumers=64, calls=60, windows=5, warm=150, pool=64):
     """The production entry (TensorStreamConverter, reference tensor_stream/tensor_stream.py:248-291) at BASELINE config C5's shape:
     `n_consumers` consumers of ONE converter on a synthetic 4K source, served by read_many() -- one hand-off and ONE batched launch
-    per published frame, every consumer its own tensor.  Outside the timed region; wall-clock rate including the Python host side."""
+    per published frame, every consumer its own tensor.  Outside the timed region; wall-clock rate including the Python host side.
+
+    The source cycles through `pool` DISTINCT 4K frames (64 x 12.4 MB = 796 MB, three times the 256 MiB Infinity Cache), so the frame a call
+    converts comes from HBM; its 64 consumers then share it (that IS C5's shape: 64 consumers of one stream) -- 63 of the 64 source reads of a call
+    are cache hits.  `hbm_frac` therefore prices the bytes that really move per call (one source frame + 64 outputs); the ROI-formula figure
+    (64 x 15.2 MB per call) is reported as `alg_frac` and says how well the host side keeps the GPU fed, not what the HBM does.
+    The measured windows run with the cyclic garbage collector frozen and disabled (a full collection is ~40 ms: at ~650 calls per collection it
+    used to land in one window of five); every window is listed."""
+    import gc
     import torch
     import tensor_stream as ts
     spec = WORKLOADS["c5"]
-    r = ts.TensorStreamConverter(f"synthetic://{spec[0]}x{spec[1]}?seed=3&frames=0&fps=100000&pool=3", max_consumers=n_consumers, cuda_device=dev,
+    r = ts.TensorStreamConverter(f"synthetic://{spec[0]}x{spec[1]}?seed=3&frames=0&fps=100000&pool={pool}", max_consumers=n_consumers, cuda_device=dev,
                                  framerate_mode=ts.FrameRate.FAST)
     r.initialize()
     r.start()
     names = [f"consumer{i}" for i in range(n_consumers)]
     kw = dict(width=spec[4][0], height=spec[4][1], resize_type=RESIZE[spec[5]], pixel_format=FOURCC[spec[6]], planes_pos=PLANES[spec[7]], normalization=spec[8])
-    # Host-side wall clock through the Python interpreter: the first ~100 calls run slower in some processes (the caching allocator
-    # settling on its 177 MB batch tensors) and a full Python garbage collection (every ~650 calls at this allocation rate, ~40 ms)
-    # lands in one window or another -- so: a long warm-up, several short windows, the MEDIAN window reported, all of them listed.
     dts = []
+    gc_was = gc.isenabled()
     try:
         for _ in range(warm):
             r.read_many(names, **kw)
         torch.cuda.synchronize()
+        gc.collect()
+        gc.freeze()
+        gc.disable()
         for _ in range(windows):
             t0 = time.perf_counter()
             for _ in range(calls):
@@ -210,15 +219,37 @@ def facade_leg(dev, n_consumers=64, calls=60, windows=5, warm=150):
             torch.cuda.synchronize()
             dts.append(time.perf_counter() - t0)
     finally:
+        if gc_was:
+            gc.enable()
+        gc.unfreeze()
         r.stop()
     bpf = algorithmic_bytes(spec[0], spec[1], spec[3], spec[4], spec[8])
-    frac = lambda dt: round(n_consumers * calls / dt * bpf / 1e9 / HBM_PEAK_GBS, 4)
+    src_bytes = spec[0] * spec[1] * 3 // 2
+    moved_per_call = src_bytes + n_consumers * (bpf - src_bytes)  # one source frame from HBM + every consumer's output
+    alg = lambda dt: round(n_consumers * calls / dt * bpf / 1e9 / HBM_PEAK_GBS, 4)
+    moved = lambda dt: round(calls / dt * moved_per_call / 1e9 / HBM_PEAK_GBS, 4)
     dt = sorted(dts)[len(dts) // 2]
     rate = n_consumers * calls / dt
-    return {"entry": "TensorStreamConverter.read_many", "workload": "c5", "consumers": n_consumers, "conversions_per_s": round(rate, 1),
-            "hbm_frac": frac(dt), "ms_per_call": round(dt * 1e3 / calls, 4), "windows_hbm_frac": [frac(x) for x in dts],
-            "note": f"one batched launch per published frame; wall clock incl. the Python host side; median of {windows} windows of {calls} calls after {warm} warm-up calls; "
-                    "every consumer converts the same source frame"}
+    return {"entry": "TensorStreamConverter.read_many", "workload": "c5", "consumers": n_consumers, "distinct_source_frames": pool,
+            "source_pool_MiB": round(pool * src_bytes / 2**20, 1), "conversions_per_s": round(rate, 1),
+            "hbm_frac": moved(dt), "alg_frac": alg(dt), "ms_per_call": round(dt * 1e3 / calls, 4), "windows_alg_frac": [alg(x) for x in dts],
+            "note": f"one batched launch per published frame; wall clock incl. the Python host side; median of {windows} windows of {calls} calls after {warm} warm-up "
+                    "calls, garbage collector frozen; hbm_frac = (one source frame + 64 outputs) per call: the 64 consumers of a call share their source frame"}
+
+
+def latency_leg(spec, iters=2000):
+    """Single-frame latency of VideoProcessor::Convert through the C++ class (tensor-stream_amd/cpp/vpp_latency.cpp): the only quantity the
+    reference publishes is a latency (getFrame 3 +- 3 ms, tests/src/WrapperTests.cpp:303-309).  Its own process, after the timed region."""
+    exe = os.path.join(ROOT, "tensor-stream_amd", "lib", "vpp_latency")
+    if not os.path.isfile(exe):
+        return {"error": "tensor-stream_amd/lib/vpp_latency is not built (make -C tensor-stream_amd/cpp)"}
+    src_w, src_h, _pitch, _crop, dst, rt, fcc, planes, norm = spec
+    cmd = [exe, str(src_w), str(src_h), str(dst[0]), str(dst[1]), str(RESIZE[rt]), str(FOURCC[fcc]), str(PLANES[planes]), "1" if norm else "0", str(iters)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"vpp_latency exited {p.returncode}: {p.stderr[-200:]}"}
+    return json.loads(lines[-1])
 
 
 _SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
@@ -842,6 +873,10 @@ def run(args):
                 res["config"]["facade"] = facade_leg(0)
             except Exception as e:
                 res["config"]["facade"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                res["config"]["latency"] = latency_leg(spec)
+            except Exception as e:
+                res["config"]["latency"] = {"error": f"{type(e).__name__}: {e}"}
         if others is not None:
             res["config"]["other_resize_types"] = others
         if other_wl is not None:

@@ -71,3 +71,15 @@ def test_force_dist_world1_nccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
                        env=_env(TSVPP_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=600)
     _check(p)
+
+
+def test_single_frame_latency_tool():
+    """tensor-stream_amd/cpp/vpp_latency (bench.py's `config.latency` leg): VideoProcessor::Convert / ConvertInto / hipGraph replay of one 1080p frame."""
+    exe = os.path.join(ROOT, "tensor-stream_amd", "lib", "vpp_latency")
+    p = subprocess.run([exe, "1920", "1080", "1280", "720", "1", "2", "0", "1", "300"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("convert_us", "convert_into_us", "graph_us"):
+        assert res[k] is not None and 0 < res[k]["min"] <= res[k]["p50"] <= res[k]["p99"], (k, res)
+    assert res["convert_into_us"]["p50"] < 3000   # the reference accepts 3 +- 3 ms for getFrame; one launch + a stream sync is tens of microseconds
+    print("\n" + json.dumps(res))
