@@ -26,6 +26,7 @@
 // that every store instruction writes a contiguous run), NV12, Y800.  fp32 outputs stay on vpp_bilinear_kernel: it sits on the
 // HBM floor of its write pattern already, and 8 fp32 columns per lane would split every line between two store instructions.
 #include "vpp_device.h"
+#include "vpp_r32_store.h"
 
 #pragma clang fp contract(off)
 
@@ -349,6 +350,34 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         return;
     }
 
+    if constexpr (OUT == O_F32_PLANAR || OUT == O_F32_MERGED || OUT == O_NV12_F32 || OUT == O_Y800_F32 || OUT == O_HSV_F32) {
+        // fp32 flavours (round 4): the tile's resized values as packed bytes, then the shared output side of the 8 x 4 streaming tiles (vpp_r32_store.h:
+        // planar rows dealt out between the lanes by shuffles before the colour conversion, merged rows exchanged through LDS -- whole-line stores)
+        uint32_t ylo[4], yhi[4], clo[2] = { 0x80808080u, 0x80808080u }, chi[2] = { 0x80808080u, 0x80808080u };
+        {
+            float yf[8];
+            r32_row<KIND, P2, false, false>(ys[r32_first<P2>(0)], ys[r32_first<P2>(0) + 1], yf);
+            ylo[0] = pack_u8x4(yf[0], yf[1], yf[2], yf[3]); yhi[0] = pack_u8x4(yf[4], yf[5], yf[6], yf[7]);
+            r32_row<KIND, P2, false, true>(ys[r32_first<P2>(1)], ys[r32_first<P2>(1) + 1], yf);
+            ylo[1] = pack_u8x4(yf[0], yf[1], yf[2], yf[3]); yhi[1] = pack_u8x4(yf[4], yf[5], yf[6], yf[7]);
+            r32_row<KIND, P2, false, false>(ys[r32_first<P2>(2)], ys[r32_first<P2>(2) + 1], yf);
+            ylo[2] = pack_u8x4(yf[0], yf[1], yf[2], yf[3]); yhi[2] = pack_u8x4(yf[4], yf[5], yf[6], yf[7]);
+            r32_row<KIND, P2, false, true>(ys[r32_first<P2>(3)], ys[r32_first<P2>(3) + 1], yf);
+            ylo[3] = pack_u8x4(yf[0], yf[1], yf[2], yf[3]); yhi[3] = pack_u8x4(yf[4], yf[5], yf[6], yf[7]);
+        }
+        if constexpr (!kLumaOnly<OUT>) {
+            float uvf[8];
+            r32_row<KIND, P2, true, false>(cs[0], cs[1], uvf);
+            clo[0] = pack_u8x4(uvf[0], uvf[1], uvf[2], uvf[3]); chi[0] = pack_u8x4(uvf[4], uvf[5], uvf[6], uvf[7]);
+            r32_row<KIND, P2, true, true>(cs[r32_first<P2>(1)], cs[r32_first<P2>(1) + 1], uvf);
+            clo[1] = pack_u8x4(uvf[0], uvf[1], uvf[2], uvf[3]); chi[1] = pack_u8x4(uvf[4], uvf[5], uvf[6], uvf[7]);
+        }
+        const int run_len = min(d.tx, 64), run_m = (int)threadIdx.x & (run_len - 1);
+        const int run_a = min(run_len, (d.dst_w - (j0 - R32_COLS * run_m)) / R32_COLS);
+        r32_store_tile<OUT>(d, out, ylo, yhi, clo, chi, i0, j0, run_m, run_a);
+        return;
+    }
+
     // merged uint8: the lanes of a run (the lanes of a wave that share the output rows) exchange their 24-byte row pieces through LDS
     // so that the run's 24 A contiguous bytes leave as 16-byte stores (cf. MergedRun, vpp_device.h)
     __shared__ __attribute__((aligned(16))) uint8_t slab[OUT == O_U8_MERGED ? MAX_THREADS * 24 : 16];
@@ -425,6 +454,7 @@ static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTabl
     switch (out) {
 #define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
         TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8) TSVPP_R32(O_YUV444_U8)
+        TSVPP_R32(O_F32_PLANAR) TSVPP_R32(O_F32_MERGED) TSVPP_R32(O_NV12_F32) TSVPP_R32(O_Y800_F32) TSVPP_R32(O_HSV_F32)
 #undef TSVPP_R32
     default: return hipErrorInvalidValue;
     }
@@ -440,7 +470,7 @@ hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTabl
         if (d.r32 < 1 || d.r32 > 6) return hipErrorInvalidValue;
         info->kernel = names[d.r32 - 1];
         info->grid = (int)grid.x;
-        info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : 16;
+        info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : (out == O_F32_MERGED || out == O_HSV_F32) ? MAX_THREADS * 96 : 16;
         return hipSuccess;
     }
     switch (d.r32) {

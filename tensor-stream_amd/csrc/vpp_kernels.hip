@@ -964,9 +964,7 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
         return launch_point<OUT>(d, t, lds_bytes, stream, info);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_DOWN || MODE == M_NEAREST) {
-        if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED || OUT == O_NV12_U8 || OUT == O_Y800_U8) {
-            if (d.r32) return launch_bilinear_r32((OutKind)OUT, d, t, stream, info);
-        }
+        if (d.r32 >= 1 && d.r32 <= 6) return launch_bilinear_r32((OutKind)OUT, d, t, stream, info);
     }
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
@@ -1408,7 +1406,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
     const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8);
     d.r32 = 0;
-    if (d.r32_pref && u8_flavour && vec && !d.force_gather && d.in_aligned4 && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
+    // fp32 flavours (round 4, through the shared output side vpp_r32_store.h).  Measured (profiles/r04_r32_f32_ab.txt): the streaming kernel ties or loses
+    // against the LDS kernels for RGB / BGR fp32 (AREA 1080p -> 720p 0.681 vs 0.683, 4K -> 1080p 0.65 vs 0.72, BILINEAR 0.69 vs 0.77) and wins for HSV,
+    // whose three divisions per pixel make the launch VALU-bound (AREA 0.56 -> 0.65): HSV takes it, the rest only under TSVPP_R32=2
+    const bool r32_f32 = f32_out && out < O_COUNT && (out == O_HSV_F32 || d.r32_pref == 2);
+    if (d.r32_pref && (u8_flavour || r32_f32) && vec && !d.force_gather && d.in_aligned4 && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
         if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) {
             if (mode == M_BILINEAR) d.r32 = 1;
             else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 2 && d.ny == 2 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 2; // rows {1, 1/2}, {1/2, 1}
@@ -1433,6 +1435,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         if (!(d.shape_tx > 0 && d.shape_ty > 0)) { // measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16
             d.tx = 64;
             d.ty = 4;
+            if (d.r32 < 7 && f32_out) d.ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
             if (d.r32 < 7 && out == O_YUV444_U8) {
                 // the one VALU-bound flavour of the 2x2-tap streaming kernel (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280
                 // columns = 2.5 rows of 64 threads: 0.465 -> 0.567 on 32 x 4 (profiles/r04_r32_shape_1280.txt); the other flavours do not care

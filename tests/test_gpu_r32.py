@@ -168,3 +168,31 @@ def test_r21_fuzz(vpp, oracle, chunk):
         fourcc, planes = [(RGB24, 0), (RGB24, 1), (BGR24, 0), (BGR24, 1), (NV12, 1), (Y800, 1), (UYVY, 1), (YUV444, 1)][int(rng.integers(0, 8))]
         y, uv = synth_nv12(w, h, seed=9000 + 100 * chunk + k, pitch=pitch)
         check(vpp, oracle, y, uv, w, (dw, dh), fourcc=fourcc, planes=planes, n=int(rng.choice([1, 1, 2])), rt=int(rng.choice([NEAREST, BILINEAR, AREA])))
+
+
+F32_FLAVOURS = [(BGR24, 0), (RGB24, 1), (NV12, 1), (Y800, 1), (6, 1)]  # fp32 planar / merged, NV12, Y800, HSV
+
+
+@pytest.mark.parametrize("src,pitch,two", [((960, 540), 960, False), ((1280, 720), 1280, True), ((444, 66), 444, False), ((456, 66), 460, False), ((48, 24), 48, True)])
+@pytest.mark.parametrize("fourcc,planes", F32_FLAVOURS)
+@pytest.mark.parametrize("rt", [AREA, NEAREST, BILINEAR])
+def test_r32_fp32_flavours(oracle, src, pitch, two, fourcc, planes, rt, monkeypatch):
+    """Round 4: the streaming kernel has fp32 flavours too (the resized values as packed bytes through the shared output side, vpp_r32_store.h).  By default
+    only HSV takes them (VALU-bound: measured faster); TSVPP_R32=2 routes every fp32 flavour there -- all of them are checked under that setting."""
+    import tensor_stream as ts
+    monkeypatch.setenv("TSVPP_R32", "2")
+    v = ts.VideoProcessor(device=0)
+    try:
+        y, uv = synth_nv12(src[0], src[1], seed=src[0] + fourcc + planes + rt, pitch=pitch)
+        dst = (src[0] // 2, src[1] // 2) if two else (src[0] * 2 // 3, src[1] * 2 // 3)
+        check(v, oracle, y, uv, src[0], dst, fourcc=fourcc, planes=planes, rt=rt, norm=True)
+    finally:
+        v.Close()
+
+
+def test_r32_fp32_default_routing_and_batches(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=32, pitch=2048)
+    for rt in (AREA, NEAREST, BILINEAR):
+        check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=6, planes=1, rt=rt, norm=True, n=64)                # HSV: the streaming kernel
+        check(vpp, oracle, y, uv, 1920, (960, 540), fourcc=6, planes=1, rt=rt, norm=True, n=3)
+        check(vpp, oracle, y, uv, 1920, (1280, 720), fourcc=BGR24, planes=0, rt=rt, norm=True, r32=False)       # RGB / BGR fp32: the LDS kernels
