@@ -216,7 +216,13 @@ __device__ __forceinline__ RowPairGeo rows_from_lds(const YEntry *ytab, const YE
     }
     return g;
 }
-template <int OUT>
+// TAP22: the weights in the tables are those of LaunchDesc::tap22 (AREA down-scale at 3 : 2 or 2 : 1) and the value is the weighted sum divided
+// by its weight total, truncated (area_quot with the one reciprocal of the request: the dyadic AREA kernels' exact division) instead of >> 8.
+template <bool TAP22> __device__ __forceinline__ float win_value(uint32_t sum, float rcp) {
+    if constexpr (TAP22) return area_quot(sum, 0, 0, rcp);
+    else return (float)((sum >> 8) & 255u);
+}
+template <int OUT, bool TAP22 = false>
 __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, const uint8_t *lds_y, const uint8_t *lds_uv, const WinColumns &k,
                                                          const RowPairGeo &g, typename OutT<OUT>::type *out, int i0, int j0) {
     float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
@@ -229,8 +235,8 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
             const uint32_t tv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, sv), k.cw[c], 0u, false);
             const uint32_t bu = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, su), k.cw[c], 0u, false);
             const uint32_t bv = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, sv), k.cw[c], 0u, false);
-            Uf[c] = (float)((vpair(tu, bu, g.cwy) >> 8) & 255u);
-            Vf[c] = (float)((vpair(tv, bv, g.cwy) >> 8) & 255u);
+            Uf[c] = win_value<TAP22>(vpair(tu, bu, g.cwy), d.area_rcp);
+            Vf[c] = win_value<TAP22>(vpair(tv, bv, g.cwy), d.area_rcp);
         }
     }
 #pragma unroll
@@ -240,7 +246,7 @@ __device__ __forceinline__ void bilinear_win_thread_tile(const LaunchDesc &d, co
         for (int c = 0; c < PXW; c++) {
             const uint32_t tt = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(T.hi, T.lo, k.sel[c]), k.w[c], 0u, false);
             const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(B.hi, B.lo, k.sel[c]), k.w[c], 0u, false);
-            Yf[r][c] = (float)((vpair(tt, bb, g.wy[r]) >> 8) & 255u);
+            Yf[r][c] = win_value<TAP22>(vpair(tt, bb, g.wy[r]), d.area_rcp);
         }
     }
     color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
@@ -291,6 +297,10 @@ __device__ __forceinline__ void bilinear_winf_thread_tile(const LaunchDesc &d, c
     color_store_tile<OUT, true, true>(Yf, Uf, Vf, d, out, i0, j0, PXW);
 }
 
+// Integer weights of an axis index for the other users of the integer window tile (LaunchDesc::tap22): packed (w0 | w1 << 16)
+__device__ __forceinline__ uint32_t tap22_weights(int kind, int idx) {
+    return kind == 1 ? ((idx & 1) ? (1u | (2u << 16)) : (2u | (1u << 16))) : (1u | (1u << 16));
+}
 // table weight field: the float weight, or for the integer tiles the packed pair (16 - 16 w) | (16 w) << 16
 __device__ __forceinline__ float table_weight(const LaunchDesc &d, float w) {
     const uint32_t k16 = (uint32_t)(w * 16.0f);
@@ -337,26 +347,26 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
         if (e < tw) {
             axis2<AREAUP>(f.j_first + e, d.xr, d.src_w, p, w);
             const uint32_t k16 = (uint32_t)(w * 16.0f);
-            xtab[e] = XEntry{ p - f.xlo, d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w };
+            xtab[e] = XEntry{ p - f.xlo, d.tap22 ? __uint_as_float(tap22_weights(d.tap22, f.j_first + e)) : d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w };
         } else if (e < tw + (tw >> 1)) {
             const int k = e - tw;
             axis2<AREAUP>((f.j_first >> 1) + k, d.xr, d.src_w, p, w);
             const uint32_t k16 = (uint32_t)(w * 16.0f);
-            cxtab[k] = XEntry{ 2 * (p - f.cxlo), d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w };
+            cxtab[k] = XEntry{ 2 * (p - f.cxlo), d.tap22 ? __uint_as_float(tap22_weights(d.tap22, (f.j_first >> 1) + k)) : d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w };
         } else if (e < tw + (tw >> 1) + th) {
             const int k = e - tw - (tw >> 1);
             axis2<AREAUP>(f.i_first + k, d.yr, d.src_h, p, w);
             const uint32_t k16 = (uint32_t)(w * 16.0f);
             const int r0 = p - f.ylo, r1 = ((p + 1 >= d.src_h) ? p : p + 1) - f.ylo; // y + 1 >= height -> same row
             ytab[k] = YEntry{ r0 * py.lp + ((py.m0 + r0 * py.pm) & 15), r1 * py.lp + ((py.m0 + r1 * py.pm) & 15),
-                              d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
+                              d.tap22 ? __uint_as_float(tap22_weights(d.tap22, f.i_first + k)) : d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
         } else {
             const int k = e - tw - (tw >> 1) - th;
             axis2<AREAUP>((f.i_first >> 1) + k, d.yr, d.src_h, p, w);
             const uint32_t k16 = (uint32_t)(w * 16.0f);
             const int r0 = p - f.cylo, r1 = ((p + 1 >= chh) ? p : p + 1) - f.cylo;
             cytab[k] = YEntry{ r0 * puv.lp + ((puv.m0 + r0 * puv.pm) & 15), r1 * puv.lp + ((puv.m0 + r1 * puv.pm) & 15),
-                               d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
+                               d.tap22 ? __uint_as_float(tap22_weights(d.tap22, (f.i_first >> 1) + k)) : d.bil_int ? __uint_as_float((16u - k16) | (k16 << 16)) : w, 0 };
         }
     }
     if (d.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA chunks have landed
@@ -390,6 +400,12 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_kernel(const LaunchD
             const int lyr = ly * d.rpt + rp, i0 = f.i_first + lyr * PXH;
             if (i0 >= d.dst_h) break;
             const RowPairGeo g = rows_from_lds(ytab, cytab, lyr);
+            if constexpr (!AREAUP) {
+                if (d.tap22) {
+                    bilinear_win_thread_tile<OUT, true>(d, lds_y, lds_uv, k, g, (T *)t.out[id.frame], i0, j0);
+                    continue;
+                }
+            }
             if (d.bil_int == 2) bilinear_win_thread_tile<OUT>(d, lds_y, lds_uv, k, g, (T *)t.out[id.frame], i0, j0);
             else bilinear_winf_thread_tile<OUT>(d, lds_y, lds_uv, k, g, (T *)t.out[id.frame], i0, j0);
         }
@@ -719,7 +735,7 @@ hipError_t launch_bilinear(bool areaup, OutKind out, const LaunchDesc &din, cons
         lds_bytes -= (cols + cols / 2) * sizeof(XEntry) + (rows + rows / 2) * sizeof(YEntry);
     }
     if (info) {
-        info->kernel = areaup ? "vpp_bilinear_kernel<areaup,OUT>" : "vpp_bilinear_kernel<bilinear,OUT>";
+        info->kernel = areaup ? "vpp_bilinear_kernel<areaup,OUT>" : d.tap22 ? "vpp_bilinear_kernel<bilinear,OUT>[area-weights]" : "vpp_bilinear_kernel<bilinear,OUT>";
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         info->geo = d.geo;

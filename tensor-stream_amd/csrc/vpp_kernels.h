@@ -131,6 +131,10 @@ struct LaunchDesc {
     // cross-over (40 taps per value), constants since the A/B runs of round 3.  Its LDS sizes travel in bc_wave_bytes / bc_ring_bytes.
     int area_stream_pref, area_stream, as_nk, as_rows, as_min_taps, as_ones_x, as_two; // as_ones_x: column taps 1 .. as_ones_x - 1 weigh 1.0f in every table row; as_two: 1 = a wave's tile is 128 columns wide (two per lane), 0 = 64 (large ratios)
     int r32_pref, r32; // streaming 3 : 2 / 2 : 1 kernels: BILINEAR / AREA / NEAREST for uint8 outputs allowed (TSVPP_R32) / chosen by launch_fused (1..6: vpp_bilinear_r32.hip; 7, 8: BICUBIC, vpp_bicubic_r32.hip)
+    // The 2x2-tap kernel's integer window tile with another weight pattern (chosen by launch_fused; vpp_bilinear.hip): at exactly 3 : 2 / 2 : 1 the AREA
+    // down-scale taps the SAME two samples per axis as BILINEAR -- only the integer weights and the final division differ.
+    // 0 = off; 1 = 3 : 2 (weights (2,1) / (1,2) by index parity, sum / 9); 2 = 2 : 1 ((1,1), sum / 4).  The divisor travels as area_rcp.
+    int tap22;
     int copy16;        // no resize, Y800 / NV12 uint8 outputs: the planes are copied 16 bytes per lane (vpp_copy16_kernel), chosen by launch_fused
     GeoCache *geo_cache;
 };

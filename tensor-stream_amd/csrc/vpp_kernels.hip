@@ -1062,6 +1062,28 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     LaunchDesc d = din;
     d.rpt = 1;
     d.bicubic_int = 0;
+    // AREA down-scale at exactly 3 : 2 / 2 : 1 with fp32 RGB / BGR / NV12 outputs: it taps the SAME two samples per axis as BILINEAR at that ratio
+    // ((int)(r j) == floor((j + 0.5) r - 0.5) for r = 1.5 and 2), so it runs on the 2x2-tap kernel's integer window tile with its own integer weights and a
+    // division instead of the shift (LaunchDesc::tap22, vpp_bilinear.hip).  Same-box A/B (profiles/r04_tap22_ab.txt): 1080p -> 720p planar 0.692 -> 0.766
+    // (vpp_area_dyadic_kernel before), merged 0.699 -> 0.715, NV12 0.692 -> 0.722, 4K -> 1080p 0.717 -> 0.736 (vpp_area_box_kernel<2> before), merged
+    // 0.731 -> 0.782, 1080p -> 540p 0.718 -> 0.750, 4K -> 1440p 0.700 -> 0.762.  Not taken: Y800 (0.623 -> 0.593), NEAREST (measured with weights (1, 0):
+    // 0.689 -> 0.678, merged 0.702 -> 0.630 -- the point sampler reads fewer rows), uint8 outputs and HSV (the streaming kernel below).
+    // TSVPP_BILINEAR_INT=0 / 2 switch it off.
+    d.tap22 = 0;
+    {
+        const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32);
+        const bool r32x = 2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h, r21 = d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h;
+        // (4 k + 2 columns: the tail launch samples by MODE)
+        if (f32 && vec && !d.force_gather && d.bil_int_pref == 1 && d.r32_pref != 2 && (r32x || r21) && (d.dst_w & 3) == 0 && mode == M_AREA_DOWN && d.qx && d.qy &&
+            d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f && ((r32x && d.nx == 2 && d.ny == 2) || (r21 && d.nx == 1 && d.ny == 1)))
+            d.tap22 = r32x ? 1 : 2;
+        if (d.tap22) {
+            mode = M_BILINEAR;
+            d.w_dyadic = 1;
+            d.point_kind = PK_NONE;
+            d.geo_pref = 0; // (the host-built geometry tables carry BILINEAR's weights)
+        }
+    }
     d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref) ? 1 : 0;
     // window form (one aligned 12-byte read per source row instead of byte reads): the four columns of a thread must span <= 8
     // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form

@@ -72,8 +72,10 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (640, 480), A, "vpp_area_box_kernel<6,0"),            # 6 x 4.5: integer horizontally, dyadic rows
     ((3840, 2160), (768, 432), A, "vpp_area_box_kernel<5,1"),            # 5 x 5
     ((1920, 1080), (480, 360), A, "vpp_area_dyadic_kernel<1,3"),        # 4 x 3: the vertical ratio is below the direct threshold
-    ((1920, 1080), (1280, 720), A, "vpp_area_dyadic_kernel<1,2"),       # 1.5: dyadic weights, LDS
-    ((1920, 1080), (960, 540), A, "vpp_area_box_kernel<2,1"),           # 2 x 2 and 3 x 3: the box kernel as well (round 2: measured faster than the LDS kernel)
+    ((1920, 1080), (1280, 720), A, "vpp_bilinear_kernel<bilinear,OUT>[area-weights]"),  # fp32 at 3 : 2 / 2 : 1: the 2x2-tap kernel with AREA's weights (round 4)
+    ((1920, 1080), (1536, 864), A, "vpp_area_dyadic_kernel<1,2"),       # 1.25: dyadic weights, LDS
+    ((1920, 1080), (960, 540), A, "vpp_bilinear_kernel<bilinear,OUT>[area-weights]"),
+    ((1924, 1084), (962, 542), A, "vpp_area_box_kernel<2,1"),           # 2 x 2 (4 k + 2 columns) and 3 x 3: the box kernel as well (round 2: measured faster than the LDS kernel)
     ((1920, 1080), (640, 360), A, "vpp_area_box_kernel<3,1"),
     ((1920, 1080), (960, 360), A, "vpp_area_box_kernel<2,0"),           # 2 x 3
     ((2560, 1440), (1920, 1080), A, "vpp_areaf_kernel<2,2"),            # 4/3: float weights, 2 x 2 taps
