@@ -1113,7 +1113,8 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // whole rows 170 us.  The kernel follows: 1080p -> 720p 164.7 us on 128 x 32 tiles (0.688 of 8 TB/s), 151.6 us on
     // 256 x 8 (0.748) -- shape sweep in profiles/r02_shape_sweep.txt.  So: 256-wide, 8-row tiles wherever the output width
     // fills them (a half-empty last tile column costs more than the pattern gains: 1920-wide outputs stay on 128).
-    if (two_tap && f32_out && d.dst_w % 256 == 0) {
+    // (the point samplers write the same pattern: NEAREST 1080p -> 720p 0.770 -> 0.795 on 64 x 4, profiles/r04_shape_sweep_misc.txt)
+    if ((two_tap || (d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC))) && f32_out && d.dst_w % 256 == 0) {
         shapes[3][0] = shapes[2][0]; shapes[3][1] = shapes[2][1];
         shapes[2][0] = shapes[1][0]; shapes[2][1] = shapes[1][1];
         shapes[1][0] = shapes[0][0]; shapes[1][1] = shapes[0][1];
