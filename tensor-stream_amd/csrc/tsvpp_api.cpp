@@ -158,6 +158,20 @@ bool all_weights_zero(Mode m, int dst_w, int dst_h, float xr, float yr, int src_
     return remember(true);
 }
 
+// BILINEAR: is every weight of ONE axis zero (an odd integer ratio on that axis only -- BASELINE config C3: 1280 -> 256 columns, ratio 5, rows at
+// 2.8125)?  The taps that a zero weight multiplies need not be fetched (sample_luma / sample_chroma: LaunchDesc::wx_zero / wy_zero).
+bool axis_weights_zero(int axis, int n, int lim, float r) {
+    static thread_local GeomMemo memo;
+    if (const bool *hit = memo.find(axis, n, 0, lim, 0)) return *hit;
+    for (int o = 0; o < n; o++) {
+        int p;
+        float w;
+        bilinear_axis(o, r, lim, p, w);
+        if (w != 0.0f) return memo.put(axis, n, 0, lim, 0, false);
+    }
+    return memo.put(axis, n, 0, lim, 0, true);
+}
+
 // Is every interpolation weight of this request a multiple of 1/16?  (ratios 1.5, 2, 2.5, 4, 0.5, 1.25, 2.25 ...: then the
 // reference's float / double evaluation is exact and the integer kernels -- vpp_bicubic_int.hip, the integer thread tile of
 // the 2x2-tap kernel -- reproduce it bit for bit.)  BILINEAR and BICUBIC share one coordinate formula (src/Resize.cu:276-303,
@@ -192,6 +206,7 @@ struct Plan {
     int swap_rb = 0;
     size_t out_bytes = 0;
     int point_kind = PK_NONE;
+    int wx_zero = 0, wy_zero = 0; // BILINEAR: every weight of that axis is zero (and not of both: that is point_kind)
     int w_dyadic = 0;
     int fourcc = TSVPP_RGB24;
     bool f32 = false;
@@ -293,6 +308,11 @@ int make_plan(const tsvpp_params *p, int in_w, int in_h, Plan &pl) {
     if (pl.mode == M_NEAREST) pl.point_kind = PK_NEAREST;
     else if ((pl.mode == M_BILINEAR || pl.mode == M_BICUBIC) && all_weights_zero(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h))
         pl.point_kind = pl.mode == M_BILINEAR ? PK_BILINEAR0 : PK_BICUBIC0;
+    pl.wx_zero = pl.wy_zero = 0;
+    if (pl.mode == M_BILINEAR && pl.point_kind == PK_NONE) {
+        pl.wx_zero = axis_weights_zero(0, pl.dst_w, pl.src_w, pl.xr) ? 1 : 0;
+        pl.wy_zero = (!pl.wx_zero && axis_weights_zero(1, pl.dst_h, pl.src_h, pl.yr)) ? 1 : 0;
+    }
     pl.w_dyadic = ((pl.mode == M_BICUBIC || pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) && pl.point_kind == PK_NONE &&
                    weights_dyadic(pl.mode, pl.dst_w, pl.dst_h, pl.xr, pl.yr, pl.src_w, pl.src_h)) ? 1 : 0;
     pl.fourcc = p->fourcc;
@@ -356,6 +376,8 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.yr = pl.yr;
     d.swap_rb = pl.swap_rb;
     d.point_kind = pl.point_kind;
+    d.wx_zero = pl.wx_zero;
+    d.wy_zero = pl.wy_zero;
     d.k = ctx->coeffs;
     d.force_gather = ctx->force_gather;
     d.nt_stores = ctx->nt_stores;

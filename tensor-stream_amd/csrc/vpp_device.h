@@ -194,6 +194,18 @@ __device__ __forceinline__ int sample_luma(const S &s, const LaunchDesc &d, int 
         }
         int xd = (x + 1 >= s.w) ? 0 : 1;
         int y2 = (y + 1 >= s.h) ? y : y + 1;
+        if constexpr (MODE == M_BILINEAR) {
+            // an axis whose weights are all zero (host: odd integer ratio on that axis): the taps the zero multiplies are not fetched -- any finite
+            // value gives the same bits ((float)B * 0 == +0) -- which halves the gathers of such a request (BASELINE config C3)
+            if (d.wx_zero) {
+                const int A = s.Y(y, x), C = s.Y(y2, x);
+                return bilerp(A, A, C, C, wx, wy) & 0xff;
+            }
+            if (d.wy_zero) {
+                const int A = s.Y(y, x), B = s.Y(y, x + xd);
+                return bilerp(A, B, A, B, wx, wy) & 0xff;
+            }
+        }
         return bilerp(s.Y(y, x), s.Y(y, x + xd), s.Y(y2, x), s.Y(y2, x + xd), wx, wy) & 0xff;
     } else if constexpr (MODE == M_BICUBIC) {
         int x, y;
@@ -255,6 +267,20 @@ __device__ __forceinline__ void sample_chroma(const S &s, const LaunchDesc &d, i
         int du = (xu + 2 >= s.w) ? 0 : 2;
         int dv = (xv + 2 >= s.w) ? 0 : 2;
         int y2 = (y + 1 >= ch) ? y : y + 1;
+        if constexpr (MODE == M_BILINEAR) {
+            if (d.wx_zero) {
+                const int Au = s.UV(y, xu), Cu = s.UV(y2, xu), Av = s.UV(y, xv), Cv = s.UV(y2, xv);
+                U = bilerp(Au, Au, Cu, Cu, wx, wy) & 0xff;
+                V = bilerp(Av, Av, Cv, Cv, wx, wy) & 0xff;
+                return;
+            }
+            if (d.wy_zero) {
+                const int Au = s.UV(y, xu), Bu = s.UV(y, xu + du), Av = s.UV(y, xv), Bv = s.UV(y, xv + dv);
+                U = bilerp(Au, Bu, Au, Bu, wx, wy) & 0xff;
+                V = bilerp(Av, Bv, Av, Bv, wx, wy) & 0xff;
+                return;
+            }
+        }
         U = bilerp(s.UV(y, xu), s.UV(y, xu + du), s.UV(y2, xu), s.UV(y2, xu + du), wx, wy) & 0xff;
         V = bilerp(s.UV(y, xv), s.UV(y, xv + dv), s.UV(y2, xv), s.UV(y2, xv + dv), wx, wy) & 0xff;
     } else if constexpr (MODE == M_BICUBIC) { // src/Resize.cu:353-354

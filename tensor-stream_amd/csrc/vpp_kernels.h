@@ -80,6 +80,7 @@ struct LaunchDesc {
     int lds_span_uv, lds_rows_uv, lds_cpr_uv;
     int lds_slot_y, lds_slot_uv; // log2 of the lanes serving one staged row (register-staged path)
     uint32_t lds_magic_y, lds_magic_uv; // 2^32 / chunks-per-row + 1 (LDS-DMA path: slot -> row by multiply-high)
+    int wx_zero, wy_zero; // BILINEAR: every weight of that axis is zero (host): the samplers do not fetch the taps it multiplies
     int point_kind;   // PointKind: >= 0 when the request is a pure point sampler (host decides, see vpp_axis.h)
     int in_aligned4;  // every frame's (crop-adjusted) plane pointers and both pitches are multiples of 4
     int force_gather; // debugging / A-B: 1 = always use the global-gather kernel

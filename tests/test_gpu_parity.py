@@ -334,3 +334,16 @@ def test_consumer_pool_semantics(vpp):
     with pytest.raises(RuntimeError, match="-3"):
         v.consumer_stream("c")
     v.Close()
+
+
+@pytest.mark.parametrize("src,dst", [((1280, 720), (256, 256)),    # BASELINE C3's ROI: ratio 5 (every x weight is zero) x 2.8125
+                                     ((1280, 720), (256, 240)),    # 5 x 3: both axes (the point sampler)
+                                     ((720, 1280), (256, 256)),    # 2.8125 x 5: every y weight is zero
+                                     ((960, 540), (320, 300)),     # 3 x 1.8: zero x weights on the LDS 2x2-tap kernel
+                                     ((540, 960), (300, 320)),     # 1.8 x 3
+                                     ((1280, 360), (256, 240))])   # 5 x 1.5
+@pytest.mark.parametrize("planes,norm", [(PLANAR, True), (MERGED, False)])
+def test_bilinear_with_one_axis_of_zero_weights(vpp, oracle, src, dst, planes, norm):
+    """Odd integer ratio on ONE axis: the samplers do not fetch the taps a zero weight multiplies (LaunchDesc::wx_zero / wy_zero) -- same bits."""
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[1])
+    check(vpp, oracle, y, uv, dst=dst, resize_type=BILINEAR, fourcc=RGB24, planes=planes, normalization=norm)
