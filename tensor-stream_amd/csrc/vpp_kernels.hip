@@ -1058,6 +1058,79 @@ static hipError_t launch_m(OutKind out, bool vec, bool staged, LaunchDesc &d, co
     }
 }
 
+// ---- streaming kernels at the exact ratios 3 : 2 / 2 : 1 (vpp_bilinear_r32.hip, vpp_bicubic_r32.hip) ----------------------------------------------
+// One row per (resize mode, ratio): the kernel instance (LaunchDesc::r32) and the same-box A/B that put the row here.  What a row needs beyond the
+// exact ratio is in stream_select below.
+struct StreamRow {
+    Mode mode;
+    int p2; // twice the ratio: 3 = 3 : 2, 4 = 2 : 1
+    int r32;
+    const char *evidence;
+};
+static const StreamRow kStreamRows[] = {
+    { M_BILINEAR, 3, 1, "profiles/r02_r32_ab.txt: uint8 1080p -> 720p planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686" },
+    { M_AREA_DOWN, 3, 2, "profiles/r02_r32_ab.txt: AREA planar 0.442 -> 0.679, merged 0.418 -> 0.660 (weight rows {1, 1/2}, {1/2, 1})" },
+    { M_NEAREST, 3, 3, "profiles/r02_r32_ab.txt: NEAREST 0.624 -> 0.800" },
+    { M_BILINEAR, 4, 4, "profiles/r02_r32_ab.txt: 1080p -> 540p 0.579 -> 0.630, 4K -> 1080p merged 0.681 vs 0.684; NOT planar >= 1.5 Mpixel (0.721 on the LDS kernel vs 0.688)" },
+    { M_AREA_DOWN, 4, 5, "profiles/r02_r32_ab.txt: 4K -> 1080p AREA 0.558 -> 0.684, merged 0.430 -> 0.623 (one weight row {1, 1})" },
+    { M_NEAREST, 4, 6, "profiles/r02_r32_ab.txt: NEAREST merged 0.83 -> 0.99" },
+    { M_BICUBIC, 3, 7, "profiles/r04_bicubic_r32_ab.txt: 1080p -> 720p fp32 planar 0.670 -> 0.711, uint8 merged 0.362 -> 0.548, fp32 merged 0.573 -> 0.702" },
+    { M_BICUBIC, 4, 8, "profiles/r04_bicubic_r32_ab.txt: 4K -> 1080p fp32 planar 0.652 -> 0.730, uint8 merged 0.368 -> 0.631; 1080p -> 540p 0.619 -> 0.691" },
+};
+// The streaming kernel instance of this request, or 0.  `mode` is the mode the launch runs as (an AREA request that took the 2x2-tap integer tile,
+// LaunchDesc::tap22, arrives here as BILINEAR and is not eligible: fp32 RGB).
+static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d) {
+    if (!vec || d.force_gather || !d.in_aligned4 || (d.dst_w & 7) != 0 || (d.dst_h & 3) != 0) return 0;
+    const int p2 = (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) ? 3 : ((d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) ? 4 : 0);
+    if (!p2) return 0;
+    const bool f32_out = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32 || out == O_HSV_F32);
+    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8);
+    int r32 = 0;
+    for (const StreamRow &row : kStreamRows)
+        if (row.mode == mode && row.p2 == p2) r32 = row.r32;
+    if (!r32) return 0;
+    if (r32 >= 7) // BICUBIC: every flavour of the colour back end (TSVPP_BICUBIC_INT=2 keeps the LDS integer kernel, TSVPP_BICUBIC_COLS=2 the column kernel)
+        return (d.w_dyadic && d.bicubic_int_pref == 1 && d.bicubic_cols_pref != 2 && out < O_COUNT) ? r32 : 0;
+    // 2x2-tap kinds: uint8 flavours; fp32 flavours (round 4, through the shared output side vpp_r32_store.h) tie or lose against the LDS kernels for RGB / BGR
+    // (profiles/r04_r32_f32_ab.txt: AREA 1080p -> 720p 0.681 vs 0.683, 4K -> 1080p 0.65 vs 0.72, BILINEAR 0.69 vs 0.77) and win for HSV, whose three
+    // divisions per pixel make the launch VALU-bound (AREA 0.56 -> 0.65, BILINEAR 0.59 -> 0.67): HSV takes them, the rest only under TSVPP_R32=2
+    if (!d.r32_pref) return 0;
+    if (!(u8_flavour || (f32_out && out < O_COUNT && (out == O_HSV_F32 || d.r32_pref == 2)))) return 0;
+    if (mode == M_AREA_DOWN) { // the weight pattern the kernel instance has compiled in
+        const bool pat = d.qx && d.qy && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f && (p2 == 3 ? (d.nx == 2 && d.ny == 2) : (d.nx == 1 && d.ny == 1));
+        if (!pat) return 0;
+    }
+    if (r32 == 4 && out == O_U8_PLANAR && (long)d.dst_w * d.dst_h >= 1500000L && d.r32_pref != 2) return 0; // (see its row)
+    return r32;
+}
+// Workgroup shape of a streaming launch (thread tile = 8 columns x 4 rows).  Measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16 for
+// the uint8 flavours of the 2x2-tap kinds (profiles/r02_r32_ab.txt); the exceptions below each carry their file.
+static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int &ty) {
+    const bool f32_out = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32 || out == O_HSV_F32);
+    const int n = d.dst_w / 8; // threads per output row
+    auto waste = [&](int w) { return (double)((n + w - 1) / w * w) / (double)n - 1.0; };
+    tx = 64;
+    ty = 4;
+    if (r32 < 7) {
+        if (f32_out) ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
+        // YUV444, the one VALU-bound flavour of the 2x2-tap kinds (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280 columns = 2.5
+        // rows of 64 threads: 0.465 -> 0.567 on 32 x 4 (profiles/r04_r32_shape_1280.txt); the other flavours do not care
+        if (out == O_YUV444_U8 && waste(64) > 0.08 && waste(32) <= 0.08) {
+            tx = 32;
+            ty = 4;
+        }
+        return;
+    }
+    // BICUBIC.  uint8 outputs are VALU-bound (77 % busy, profiles/r04_bicubic_r32_pmc.txt), so idle lanes cost what they idle: 1280 columns = 160
+    // threads -- 32-wide workgroups +9 % there; 1920 and 960 columns (240 / 120 threads) lose 6.7 % of a 64-wide row and still prefer it (longer store
+    // runs).  fp32 outputs are bound by the issue of memory instructions: always 64 wide (neighbour dwords by wave shuffle instead of two loads per
+    // row) and SHORT tiles, as the 2x2-tap kernel: two thread rows (profiles/r04_bicubic_r32_shapes.txt, r04_bicubic_r32_ab.txt); HSV -- three
+    // divisions per pixel, VALU-bound again -- four (0.60 vs 0.53).
+    tx = (f32_out || waste(64) <= 0.08) ? 64 : (waste(32) <= 0.08 ? 32 : (waste(16) < waste(32) ? 16 : 32));
+    ty = f32_out ? (out == O_HSV_F32 ? 4 : 2) : 256 / tx;
+    if (ty > 8) ty = 8;
+}
+
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
     LaunchDesc d = din;
     d.rpt = 1;
@@ -1243,14 +1316,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip, below)
-    // BICUBIC at exactly 3 : 2 or 2 : 1 on both axes: the streaming kernel of vpp_bicubic_r32.hip (byte coefficients, v_dot4 on the source dwords, no
-    // LDS staging) takes every output flavour (7 / 8 = d.r32 below; TSVPP_BICUBIC_INT=2 keeps the LDS integer kernel)
-    int bc_r32 = 0;
-    if (mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref == 1 && d.bicubic_cols_pref != 2 && vec && !d.force_gather && d.in_aligned4 && out < O_COUNT &&
-        (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
-        if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) bc_r32 = 7;
-        else if (d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) bc_r32 = 8;
-    }
+    // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
+    const int stream_r32 = stream_select(mode, out, vec, d);
+    const int bc_r32 = stream_r32 >= 7 ? stream_r32 : 0;
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
     if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
@@ -1424,29 +1492,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.tx = 64;
         d.ty = 4;
     }
-    // BILINEAR at exactly 3 : 2 or 2 : 1 on both axes with uint8 outputs: the streaming kernel of vpp_bilinear_r32.hip (thread = 8 x 4 outputs
-    // from 12-byte runs of 6 + 3 source rows) -- and, with the same taps, AREA and NEAREST at that ratio.  Measured (profiles/r02_r32_ab.txt): uint8
-    // 1080p -> 720p BILINEAR planar 0.563 -> 0.687, merged 0.509 -> 0.673, NV12 0.578 -> 0.684, Y800 0.490 -> 0.686.
-    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8);
-    d.r32 = 0;
-    // fp32 flavours (round 4, through the shared output side vpp_r32_store.h).  Measured (profiles/r04_r32_f32_ab.txt): the streaming kernel ties or loses
-    // against the LDS kernels for RGB / BGR fp32 (AREA 1080p -> 720p 0.681 vs 0.683, 4K -> 1080p 0.65 vs 0.72, BILINEAR 0.69 vs 0.77) and wins for HSV,
-    // whose three divisions per pixel make the launch VALU-bound (AREA 0.56 -> 0.65): HSV takes it, the rest only under TSVPP_R32=2
-    const bool r32_f32 = f32_out && out < O_COUNT && (out == O_HSV_F32 || d.r32_pref == 2);
-    if (d.r32_pref && (u8_flavour || r32_f32) && vec && !d.force_gather && d.in_aligned4 && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0) {
-        if (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) {
-            if (mode == M_BILINEAR) d.r32 = 1;
-            else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 2 && d.ny == 2 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 2; // rows {1, 1/2}, {1/2, 1}
-            else if (mode == M_NEAREST) d.r32 = 3;
-        } else if (d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) {
-            // BILINEAR 2 : 1, planar, large outputs: the LDS kernel with geometry tables measured faster (4K -> 1080p 0.721 vs 0.688 same box;
-            // merged 0.681 vs 0.684; 1080p -> 540p 0.579 vs 0.630): streaming only below 1.5 Mpixel there (TSVPP_R32=2 forces it)
-            if (mode == M_BILINEAR) d.r32 = (out == O_U8_PLANAR && (long)d.dst_w * d.dst_h >= 1500000L && d.r32_pref != 2) ? 0 : 4;
-            else if (mode == M_AREA_DOWN && d.qx && d.qy && d.nx == 1 && d.ny == 1 && d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f) d.r32 = 5; // one row {1, 1}
-            else if (mode == M_NEAREST) d.r32 = 6;
-        }
-    }
-    if (bc_r32) d.r32 = bc_r32;
+    d.r32 = stream_r32;
     if (d.r32) {
         d.point_kind = PK_NONE;
         d.area_direct = 0;
@@ -1455,32 +1501,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.dma = 0;
         d.rpt = 1;
         d.geo = 0;
-        if (!(d.shape_tx > 0 && d.shape_ty > 0)) { // measured: 64 x 4 threads (512 x 16 pixels) +0.4..3 % over 32 x 8 and 16 x 16
-            d.tx = 64;
-            d.ty = 4;
-            if (d.r32 < 7 && f32_out) d.ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
-            if (d.r32 < 7 && out == O_YUV444_U8) {
-                // the one VALU-bound flavour of the 2x2-tap streaming kernel (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280
-                // columns = 2.5 rows of 64 threads: 0.465 -> 0.567 on 32 x 4 (profiles/r04_r32_shape_1280.txt); the other flavours do not care
-                const int n = d.dst_w / 8;
-                if ((double)((n + 63) / 64 * 64) / (double)n > 1.08 && (double)((n + 31) / 32 * 32) / (double)n <= 1.08) {
-                    d.tx = 32;
-                    d.ty = 4;
-                }
-            }
-            if (d.r32 >= 7) {
-                // The BICUBIC kernel is VALU-bound (uint8: 77 % busy, profiles/r04_bicubic_r32_pmc.txt), so lanes past the right edge cost what they
-                // idle: 1280 columns = 160 threads = 2.5 rows of 64 -- 32-wide workgroups +9 % there; 1920 and 960 columns (240 / 120 threads) lose
-                // 6.7 % of a 64-wide row and still prefer it (longer store runs).  fp32 outputs are bound by the write pattern and want SHORT
-                // tiles, as the 2x2-tap kernel does: two thread rows (profiles/r04_bicubic_r32_shapes.txt).
-                const int n = d.dst_w / 8;
-                auto waste = [&](int tx) { return (double)((n + tx - 1) / tx * tx) / (double)n - 1.0; };
-                // fp32 outputs are bound by the issue of memory instructions, not by the VALU: always 64 wide (neighbour dwords by wave shuffle)
-                d.tx = (f32_out || waste(64) <= 0.08) ? 64 : (waste(32) <= 0.08 ? 32 : (waste(16) < waste(32) ? 16 : 32));
-                d.ty = f32_out ? (out == O_HSV_F32 ? 4 : 2) : 256 / d.tx; // (HSV: three divisions per pixel, VALU-bound again -- 0.60 with four thread rows, 0.53 with two)
-                if (d.ty > 8) d.ty = 8;
-            }
-        }
+        if (!(d.shape_tx > 0 && d.shape_ty > 0)) stream_shape(d.r32, out, d, d.tx, d.ty); // (TSVPP_SHAPE overrides: shapes[0] above)
     }
     d.tx_shift = slot_shift_for(d.tx);
     if (d.r32) d.bicubic_cols = 0;
