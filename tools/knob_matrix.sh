@@ -8,6 +8,7 @@ TSVPP_DMA=0
 TSVPP_BILINEAR_INT=0
 TSVPP_BILINEAR_INT=2
 TSVPP_BICUBIC_INT=0
+TSVPP_BICUBIC_INT=2
 TSVPP_BICUBIC_COLS=2
 TSVPP_BICUBIC_COLS=0
 TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=0
