@@ -253,7 +253,7 @@ def latency_leg(spec, iters=2000):
 
 
 _SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
-_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
+_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
                  ("vpp_bicubic_cols", "vpp_bicubic_cols.hip"), ("vpp_area_box", "vpp_area_box.hip"), ("vpp_area_stream", "vpp_area_stream.hip"),
                  ("fmt_", "vpp_formats.hip")]
 
@@ -265,7 +265,8 @@ def kernel_source_files(kernel=None):
         return list(KERNEL_SOURCES)
     k = kernel.split("::")[-1]
     unit = next((f for prefix, f in _KERNEL_FILES if k.startswith(prefix)), "vpp_kernels.hip")
-    return ["tensor-stream_amd/csrc/" + unit] + _SHARED_SOURCES
+    extra = {"vpp_bicubic_r32.hip": ["vpp_bicubic_r32_core.h", "vpp_r32_store.h"], "vpp_bilinear_r32.hip": ["vpp_r32_store.h"]}.get(unit, [])
+    return ["tensor-stream_amd/csrc/" + f for f in [unit] + extra] + _SHARED_SOURCES
 
 
 def kernel_src_hash(kernel=None):
@@ -284,8 +285,8 @@ def lookup_traffic(workload, frames_per_launch, path=None, kernel=None, alg_read
 
     An entry must also be PLAUSIBLE as one kernel's traffic (round 3 published a six-kernel blend whose sum happened to land on
     1.005x): with the algorithmic split per launch given (`alg_read`, `alg_write`), the write side must be within 10 % of it and
-    the read side within 10 % of it -- or, for a sampler that skips source bytes, between 0.9x the touched source bytes
-    (`touched_read`, bench.touched_bytes) and 1.1x the ROI bytes.  Anything else is refused with the numbers in the reason."""
+    the read side between 0.9x and 1.35x of it (tile halos are re-read) -- or, for a sampler that skips source bytes, from 0.9x the touched source
+    bytes (`touched_read`, bench.touched_bytes).  Anything else is refused with the numbers in the reason."""
     path = path or os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         tr = json.load(open(path)).get(workload)
@@ -308,12 +309,16 @@ def lookup_traffic(workload, frames_per_launch, path=None, kernel=None, alg_read
         if not 0.9 * alg_write <= wr <= 1.1 * alg_write:
             return None, (f"implausible PMC entry ({tr.get('round')}): {wr} B written per launch, the launch writes {int(alg_write)} B "
                           "(more than 10 % off: not this kernel's traffic)")
+        # reads: not below what the launch must touch (-10 %), and at most 1.35x the ROI: kernels whose tiles overlap re-read a halo (the streaming BICUBIC
+        # kernel: rows -1 .. +2 around a tile's six, 1.22x; the column kernel 1.13x) -- round 3's six-kernel blend read 1.71x and wrote 0.81x
         lo = 0.9 * (min(touched_read, alg_read) if touched_read is not None else alg_read)
-        if not lo <= rd <= 1.1 * alg_read:
+        if not lo <= rd <= 1.35 * alg_read:
             return None, (f"implausible PMC entry ({tr.get('round')}): {rd} B read per launch, algorithmic {int(alg_read)} B"
-                          + (f", touched {int(touched_read)} B" if touched_read is not None else "") + " (outside the 10 % band)")
+                          + (f", touched {int(touched_read)} B" if touched_read is not None else "") + " (outside the plausible band)")
         if rd < 0.9 * alg_read:
             note = f"; reads {rd / alg_read:.3f}x the ROI bytes, explained by touched_bytes ({touched_read / alg_read:.3f}x)"
+        elif rd > 1.1 * alg_read:
+            note = f"; read {rd / alg_read:.3f}x the algorithmic bytes (tile halo re-read) / write {wr / alg_write:.4f}x"
         else:
             note = f"; read {rd / alg_read:.4f}x / write {wr / alg_write:.4f}x the algorithmic split"
     return tr["hbm_bytes_per_launch"], (f"profiles/traffic_latest.json ({tr['round']}, {tr.get('kernel_csv_name') or tr.get('kernel', 'all kernels')}, "

@@ -38,7 +38,8 @@ def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 
     ((1920, 1080), (480, 240), "vpp_area_box_kernel<4,0"),   # 4 x 4.5
     ((2560, 1440), (512, 192), "vpp_area_box_kernel<5,0"),   # 5 x 7.5
     ((1920, 1080), (240, 270), "vpp_area_box_kernel<8,0"),   # 8 x 4
-    ((1920, 1080), (960, 540), "vpp_area_box_kernel<2,1"),   # 2 x 2 and 3 x 3: below the direct threshold, the box kernel all the same
+    ((1924, 1084), (962, 542), "vpp_area_box_kernel<2,1"),   # 2 x 2 and 3 x 3: below the direct threshold, the box kernel all the same (4 k + 2 columns: 4 k
+                                                             # columns at exactly 2 : 1 with fp32 outputs are the 2x2-tap integer tile's since round 4)
     ((1920, 1080), (640, 360), "vpp_area_box_kernel<3,1"),
     ((3840, 2160), (1280, 720), "vpp_area_box_kernel<3,1"),
     ((1920, 1080), (960, 360), "vpp_area_box_kernel<2,0"),   # 2 x 3
