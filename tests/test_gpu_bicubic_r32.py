@@ -48,6 +48,13 @@ def test_full_sizes(vpp, oracle, src, dst):
     run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False)
 
 
+def test_8k_frame(vpp, oracle):
+    """7680 x 4320: 32-bit plane offsets and output offsets far from their limits, 960 / 640 threads per row."""
+    y, uv = synth_nv12(7680, 4320, seed=88)
+    run(vpp, oracle, y, uv, 7680, (5120, 2880), planes=1, norm=False)
+    run(vpp, oracle, y, uv, 7680, (3840, 2160), planes=0, norm=True)
+
+
 def test_uyvy_and_yuv444_behind_it(vpp, oracle):
     """Two-pass formats: the streaming kernel writes the NV12 intermediate."""
     y, uv = synth_nv12(960, 540, seed=8)
