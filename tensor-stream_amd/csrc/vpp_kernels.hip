@@ -1131,10 +1131,20 @@ static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int
     if (ty > 8) ty = 8;
 }
 
-hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
-    LaunchDesc d = din;
-    d.rpt = 1;
-    d.bicubic_int = 0;
+// ---- launch_fused, step by step -------------------------------------------------------------------------------------------------------------------
+// What launch_fused decides besides the LaunchDesc fields.  Each sel_* function below is one decision with the measurements that set its thresholds;
+// launch_fused calls them in order (tests/golden/describe_snapshot.json pins the outcome for 417 requests).
+struct FusedSel {
+    int shapes[5][2] = { { 32, 8 }, { 32, 4 }, { 16, 4 }, { 0, 0 }, { 0, 0 } }; // candidate workgroup shapes, largest first
+    size_t lds_budget = 40 * 1024, lds_bytes = 0, as_lds = 0;
+    bool staged = false, f32_out = false, two_tap = false;
+};
+static long fused_workgroups(const LaunchDesc &d, const int *sh, int rpt) {
+    return (long)((d.dst_w + sh[0] * PXW - 1) / (sh[0] * PXW)) * ((d.dst_h + sh[1] * PXH * rpt - 1) / (sh[1] * PXH * rpt)) * d.n_frames;
+}
+
+// 1. AREA on the 2x2-tap integer tile (may turn `mode` into M_BILINEAR)
+static void sel_tap22(Mode &mode, OutKind out, bool vec, LaunchDesc &d) {
     // AREA down-scale at exactly 3 : 2 / 2 : 1 with fp32 RGB / BGR / NV12 outputs: it taps the SAME two samples per axis as BILINEAR at that ratio
     // ((int)(r j) == floor((j + 0.5) r - 0.5) for r = 1.5 and 2), so it runs on the 2x2-tap kernel's integer window tile with its own integer weights and a
     // division instead of the shift (LaunchDesc::tap22, vpp_bilinear.hip).  Same-box A/B (profiles/r04_tap22_ab.txt): 1080p -> 720p planar 0.692 -> 0.766
@@ -1157,6 +1167,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             d.geo_pref = 0; // (the host-built geometry tables carry BILINEAR's weights)
         }
     }
+}
+
+// 2. thread-tile forms of the 2x2-tap kernel
+static void sel_two_tap_forms(Mode mode, LaunchDesc &d) {
     d.bil_int = ((mode == M_BILINEAR || mode == M_AREA_UP) && d.w_dyadic && d.bil_int_pref) ? 1 : 0;
     // window form (one aligned 12-byte read per source row instead of byte reads): the four columns of a thread must span <= 8
     // bytes, i.e. horizontal ratio <= 2 (vpp_bilinear.hip); TSVPP_BILINEAR_INT=2 keeps the byte form
@@ -1165,7 +1179,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // even below 1 (profiles/r02_bilinear_winf_ab.txt) -- used between 1 and 1.45
     d.bil_win = (!d.bil_int && (mode == M_BILINEAR || mode == M_AREA_UP) && d.xr <= 2.0f &&
                  (d.bil_win_pref == 2 || (d.bil_win_pref == 1 && d.xr > 1.0f && d.xr <= 1.45f))) ? 1 : 0;
-    d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
+}
+
+// 3. store policy
+static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
     if (d.nt_stores < 0) { // per-kernel default
         // fp32 outputs: every store instruction of a wave covers whole 128-byte lines (planar: 16 contiguous
         // bytes per lane; merged: after the in-wave exchange of MergedRun) and nothing re-reads them.  The
@@ -1174,12 +1191,19 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const bool f32_partial = !vec && (out == O_F32_MERGED || out == O_HSV_F32);
         d.nt_stores = f32_partial ? 0 : ((mode == M_NONE && f32_lines) ? 2 : 1);
     }
+}
+
+// 4. candidate workgroup shapes
+static void sel_shapes(Mode mode, OutKind out, LaunchDesc &d, FusedSel &S) {
+    bool &staged = S.staged;
+    size_t &lds_bytes = S.lds_bytes;
+    int (&shapes)[5][2] = S.shapes;
+    const size_t kLdsBudget = S.lds_budget;
+    const bool f32_out = S.f32_out, two_tap = S.two_tap;
+    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     // Candidate workgroup shapes, largest first; the staged kernels take the first whose source
     // footprint fits the LDS budget (several workgroups per CU must stay resident to overlap one
     // group's loads with another's arithmetic).
-    int shapes[5][2] = { { 32, 8 }, { 32, 4 }, { 16, 4 }, { 0, 0 }, { 0, 0 } };
-    const bool f32_out = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32 || out == O_HSV_F32);
-    const bool two_tap = (mode == M_BILINEAR || mode == M_AREA_UP);
     // The 2x2-tap kernel with fp32 outputs runs AT the HBM floor of its tile pattern, and that floor depends on the tile
     // shape (tools/membench2.hip, the headline's 22 % read / 78 % write mix with no arithmetic, 64 frames, rotating buffers):
     // 128 x 32 tiles 165 us, 128 x 16 159 us, 256 x 8 153 us (1 KiB row segments per plane, half the in-flight footprint),
@@ -1207,14 +1231,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         shapes[0][0] = d.shape_tx;
         shapes[0][1] = d.shape_ty;
     }
-    const size_t kLdsBudget = (size_t)(d.lds_budget_kb > 0 ? d.lds_budget_kb : 40) * 1024; // TSVPP_LDS_KB
-    bool staged = false;
-    size_t lds_bytes = 0;
-    auto workgroups = [&](const int *sh, int rpt) {
-        return (long)((d.dst_w + sh[0] * PXW - 1) / (sh[0] * PXW)) * ((d.dst_h + sh[1] * PXH * rpt - 1) / (sh[1] * PXH * rpt)) * d.n_frames;
-    };
-    d.tx = shapes[0][0];
-    d.ty = shapes[0][1];
+}
+
+// 5. AREA down-scale: which of the un-staged samplers (direct / box / streaming / column-per-lane), if any
+static void sel_area(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
+    size_t &as_lds = S.as_lds;
     if (mode == M_AREA_DOWN && d.qx && d.qy && vec && !d.force_gather && d.area_direct_min > 0.0f && d.xr >= d.area_direct_min &&
         d.yr >= d.area_direct_min)
         d.area_direct = 1;
@@ -1237,7 +1258,6 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // Float-weight AREA: one wave per 128-column tile, the source rows streamed through a wave-private ring (vpp_area_stream.hip).  Needs the
     // host-built divisor table, pitches that are multiples of 16 (LDS-DMA chunks), a row segment of at most 128 chunks (ratio <= ~15).
     d.area_stream = 0;
-    size_t as_lds = 0;
     // TSVPP_AREA_STREAM: 1 = from `as_min_taps` taps per value on (measured cross-over, profiles/r03_area_stream_ab*.txt), 2 = wherever it applies
     if (mode == M_AREA_DOWN && !(d.qx && d.qy) && vec && !d.force_gather && (d.area_stream_pref == 2 ||
          (d.area_stream_pref == 1 && (d.rx * d.ry >= d.as_min_taps || d.nkx > 3 || (d.area_direct != 2 && !(d.rx <= 3 && d.ry <= 3 && d.area2_pref))))) && d.area_div && d.patx4 && d.paty4 && d.nkx >= 1 && d.nkx <= 8 &&
@@ -1278,6 +1298,16 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.tx = 16;
         d.ty = d.area_cols_rows / 2;
     }
+}
+
+// 6. point samplers (NEAREST; BILINEAR / BICUBIC whose weights are all zero): one LDS row per output row
+static void sel_point(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
+    bool &staged = S.staged;
+    size_t &lds_bytes = S.lds_bytes;
+    int (&shapes)[5][2] = S.shapes;
+    const size_t kLdsBudget = S.lds_budget;
+    const bool f32_out = S.f32_out, two_tap = S.two_tap;
+    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
     if (point && vec && !d.force_gather) {
@@ -1306,21 +1336,17 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     } else {
         d.point_kind = PK_NONE;
     }
-    d.bicubic_cols = 0;
-    d.bc_sparse = 0;
-    d.bc_dma = 0;
-    // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
-    // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
-    // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
-    // 224^2 / 300^2 / 640^2, 4K -> 640x360; C3: 720p crop -> 256^2 = 14, gathers +8 %): BILINEAR gathers win from
-    // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
-    const float ratio_area = d.xr * d.yr;
-    // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip, below)
-    // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
-    const int stream_r32 = stream_select(mode, out, vec, d);
-    const int bc_r32 = stream_r32 >= 7 ? stream_r32 : 0;
-    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
-    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
+}
+
+// 7. the LDS-staged kernels (2x2-tap, integer BICUBIC, dyadic / small float AREA): first workgroup shape, rows per thread and staging layout that fit
+static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gather, LaunchDesc &d, FusedSel &S) {
+    bool &staged = S.staged;
+    size_t &lds_bytes = S.lds_bytes;
+    int (&shapes)[5][2] = S.shapes;
+    const size_t kLdsBudget = S.lds_budget;
+    const bool f32_out = S.f32_out, two_tap = S.two_tap;
+    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
+    auto workgroups = [&](const int *sh, int rpt) { return fused_workgroups(d, sh, rpt); };
     if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
@@ -1430,7 +1456,16 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             }
         }
     }
-    if (!staged) d.dma = 0;
+}
+
+// 8. the wave-per-tile BICUBIC kernel
+static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, FusedSel &S, hipStream_t stream, LaunchInfo *info) {
+    bool &staged = S.staged;
+    size_t &lds_bytes = S.lds_bytes;
+    int (&shapes)[5][2] = S.shapes;
+    const size_t kLdsBudget = S.lds_budget;
+    const bool f32_out = S.f32_out, two_tap = S.two_tap;
+    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     // BICUBIC that the integer kernel above did not take (non-dyadic weights -- or TSVPP_BICUBIC_COLS=2: every request): one wave per
     // 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane (vpp_bicubic_cols.hip).  A taller
     // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
@@ -1484,6 +1519,45 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
             d.dma = 0;
         }
     }
+}
+
+hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
+    LaunchDesc d = din;
+    d.rpt = 1;
+    d.bicubic_int = 0;
+    FusedSel S;
+    sel_tap22(mode, out, vec, d);
+    sel_two_tap_forms(mode, d);
+    d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
+    sel_store_policy(mode, out, vec, d);
+    S.f32_out = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32 || out == O_HSV_F32);
+    S.two_tap = (mode == M_BILINEAR || mode == M_AREA_UP);
+    S.lds_budget = (size_t)(d.lds_budget_kb > 0 ? d.lds_budget_kb : 40) * 1024; // TSVPP_LDS_KB
+    sel_shapes(mode, out, d, S);
+    bool &staged = S.staged;
+    size_t &lds_bytes = S.lds_bytes;
+    d.tx = S.shapes[0][0];
+    d.ty = S.shapes[0][1];
+    sel_area(mode, vec, d, S);
+    sel_point(mode, vec, d, S);
+    d.bicubic_cols = 0;
+    d.bc_sparse = 0;
+    d.bc_dma = 0;
+    // Interpolating kernels at large down-scale ratios tap only a few bytes of each source line: staging the whole
+    // footprint through LDS then moves (and waits for) mostly unused bytes with few waves in flight, while plain
+    // gathers touch each needed line once with full occupancy.  Measured cross-over (tools/matrix.sh, 1080p ->
+    // 224^2 / 300^2 / 640^2, 4K -> 640x360; C3: 720p crop -> 256^2 = 14, gathers +8 %): BILINEAR gathers win from
+    // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
+    const float ratio_area = d.xr * d.yr;
+    // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
+    const int stream_r32 = stream_select(mode, out, vec, d);
+    const int bc_r32 = stream_r32 >= 7 ? stream_r32 : 0;
+    // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
+    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
+    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
+    sel_staged(mode, vec, bicubic_staged, sparse_gather, d, S);
+    if (!staged) d.dma = 0;
+    sel_bicubic_cols(mode, vec, bc_r32, d, S, stream, info);
     const size_t bc_lds = lds_bytes;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     // ... and for the outputs that are the planes themselves (uint8 Y800 / NV12) a copy of 16 bytes per lane (vpp_copy16_kernel)
@@ -1507,7 +1581,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (d.r32) d.bicubic_cols = 0;
     if (d.bicubic_cols) lds_bytes = bc_lds;
     if (d.r32) d.area_stream = 0;
-    if (d.area_stream) lds_bytes = as_lds;
+    if (d.area_stream) lds_bytes = S.as_lds;
     const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.copy16 ? 16 : d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
     const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : (d.r32 || d.copy16) ? d.ty * 4 : d.ty * PXH * d.rpt;
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
