@@ -41,6 +41,7 @@ for _p in (ROOT, os.path.join(ROOT, "tensor-stream_amd")):
 
 import numpy as np
 
+MAX_LAUNCH = 128      # frames per launch (include/tsvpp.h: TSVPP_MAX_BATCH)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 METRIC = "1080p NV12→720p BGR24 planar fp32 frames/sec per GPU; achieved HBM GB/s vs roofline"
 
@@ -332,7 +333,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is run this many times and the median is reported; "
                     "0 = max(5, ceil(400 / steps)): SURVEY.md 8(d) asks for >= 200 timed iterations and a median of 5; 400 keep the clock ramp of the first ~25 ms out of the median")
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per 64)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per MAX_LAUNCH = 128 frames: tsvpp.h TSVPP_MAX_BATCH)")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--alias", type=int, default=0, help="DIAGNOSTIC (not a measurement of the path): bit 0 = all frames of a launch read one "
                     "input frame, bit 1 = all write one output buffer, so that reads / writes stay in cache; separates issue-bound from memory-bound kernels")
@@ -415,8 +416,8 @@ def spawn(args, argv):
 
 class _StubWork:
     def __init__(self, args):
-        self.frames_per_launch = float(min(args.batch, 64))
-        self.launches_per_step = (args.batch + 63) // 64
+        self.frames_per_launch = float(min(args.batch, MAX_LAUNCH))
+        self.launches_per_step = (args.batch + MAX_LAUNCH - 1) // MAX_LAUNCH
 
     def issue(self, i, stream):
         time.sleep(0.0005)
@@ -428,8 +429,8 @@ class StubEngine:
 
     def __init__(self, args, spec, rank):
         self.args = args
-        self.frames_per_launch = float(min(args.batch, 64))
-        self.launches_per_step = (args.batch + 63) // 64
+        self.frames_per_launch = float(min(args.batch, MAX_LAUNCH))
+        self.launches_per_step = (args.batch + MAX_LAUNCH - 1) // MAX_LAUNCH
         self.ws_mib = 0.0
         self.parity = "stub"
         self.graphs = False
@@ -482,7 +483,7 @@ class GpuWork:
         F = per_call if 0 < per_call < B else B
         self.batches = [[vpp.make_batch(ys[k:k + F], uvs[k:k + F], self.fp, out=out[k:k + F], width=src_w) for k in range(0, B, F)]
                         for (ys, uvs, out) in self.sets]
-        self.launches_per_step = ((F + 63) // 64) * (B // F) + ((B % F + 63) // 64)
+        self.launches_per_step = ((F + MAX_LAUNCH - 1) // MAX_LAUNCH) * (B // F) + ((B % F + MAX_LAUNCH - 1) // MAX_LAUNCH)
         self.frames_per_launch = B / self.launches_per_step
         self.vpp = vpp
 
@@ -560,7 +561,7 @@ class GpuEngine:
         """The kernel the timed launches dispatch (host-side dry run of the same selection: tsvpp_describe)."""
         src_w, src_h, pitch = self.spec[0], self.spec[1], self.spec[2]
         try:
-            dsc = self.ts.vpp.describe(self.fp, src_w, src_h, pitch=pitch, n_frames=int(min(self.args.batch, 64)))
+            dsc = self.ts.vpp.describe(self.fp, src_w, src_h, pitch=pitch, n_frames=int(min(self.args.batch, MAX_LAUNCH)))
             return "tsvpp::" + str(dsc.get("kernel", "?"))
         except Exception as e:
             return f"tsvpp::? ({type(e).__name__}: {e})"

@@ -54,7 +54,7 @@ enum tsvpp_fourcc { TSVPP_Y800 = 0, TSVPP_RGB24 = 1, TSVPP_BGR24 = 2, TSVPP_NV12
 enum tsvpp_planes { TSVPP_PLANAR = 0, TSVPP_MERGED = 1 };
 enum tsvpp_resize { TSVPP_NEAREST = 0, TSVPP_BILINEAR = 1, TSVPP_BICUBIC = 2, TSVPP_AREA = 3 };
 
-#define TSVPP_MAX_BATCH 64 /* frames per launch; larger batches are split */
+#define TSVPP_MAX_BATCH 128 /* frames per launch; larger batches are split (round 4: 64 -> 128; the pointer table travels in the kernarg segment: 3 KiB) */
 
 /* One NV12 frame in device memory.  Mirrors the AVFrame fields Convert() reads
  * (reference src/Crop.cu:37-38, src/Resize.cu:420-421, src/ColorConversion.cu:301):

@@ -8,7 +8,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "lib", "libtsvpp.so"))
 
-TSVPP_MAX_BATCH = 64
+TSVPP_MAX_BATCH = 128
 
 
 class NV12(ctypes.Structure):

@@ -170,7 +170,7 @@ class VideoProcessor:
     convert = Convert
 
     def convert_batch(self, ys, uvs, params, out=None, width=None, height=None):
-        """ys / uvs: 3-D uint8 tensors (n, rows, pitch) or lists of 2-D tensors; one launch per 64 frames.
+        """ys / uvs: 3-D uint8 tensors (n, rows, pitch) or lists of 2-D tensors; one launch per 128 frames.
         Returns (or fills `out`, indexed out[i]) a tensor of shape (n, ...frame shape).  NOTE the frame stride of the tensor this
         method allocates: every frame starts 16-byte aligned (the vector-store kernels need that), so when a frame's bytes are
         not a multiple of 16 (e.g. 250 x 250 x 3 uint8) the batch tensor is a strided VIEW with a padded stride(0) -- out[i] is
