@@ -57,7 +57,7 @@ RESIZE = {"NEAREST": 0, "BILINEAR": 1, "BICUBIC": 2, "AREA": 3}
 FOURCC = {"Y800": 0, "RGB24": 1, "BGR24": 2, "NV12": 3, "UYVY": 4, "YUV444": 5, "HSV": 6}
 PLANES = {"PLANAR": 0, "MERGED": 1}
 # sources whose hash stamps a PMC traffic entry (tools/traffic_json.py writes it, lookup_traffic checks it)
-KERNEL_SOURCES = ["tensor-stream_amd/csrc/vpp_kernels.hip", "tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_bicubic_int.hip", "tensor-stream_amd/csrc/vpp_bilinear.hip", "tensor-stream_amd/csrc/vpp_bilinear_r32.hip",
+KERNEL_SOURCES = ["tensor-stream_amd/csrc/vpp_kernels.hip", "tensor-stream_amd/csrc/vpp_select.hip", "tensor-stream_amd/csrc/vpp_bicubic_r32.hip", "tensor-stream_amd/csrc/vpp_bicubic_r32_core.h", "tensor-stream_amd/csrc/vpp_r32_store.h", "tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_bicubic_int.hip", "tensor-stream_amd/csrc/vpp_bilinear.hip", "tensor-stream_amd/csrc/vpp_bilinear_r32.hip",
                   "tensor-stream_amd/csrc/vpp_area_box.hip", "tensor-stream_amd/csrc/vpp_area_stream.hip", "tensor-stream_amd/csrc/vpp_bicubic_cols.hip", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h",
                   "tensor-stream_amd/csrc/vpp_formats.hip", "tensor-stream_amd/csrc/tsvpp_api.cpp"]
 

@@ -206,6 +206,10 @@ struct LaunchInfo {
 // Returns hipError_t.
 // `info` != nullptr: a dry run -- the selection is recorded there and nothing is launched.
 hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info = nullptr);
+// (vpp_kernels.hip, for vpp_select.hip) the kernel of a (mode, flavour) pair as chosen; LDS bytes of the AREA kernels' coordinate tables
+hipError_t launch_mode(Mode mode, OutKind out, bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds, hipStream_t stream, LaunchInfo *info);
+size_t area_dyadic_table_bytes(size_t cols, size_t rows);
+size_t areaf_table_bytes(size_t cols, size_t rows);
 
 // Integer BICUBIC kernel for dyadic weights (vpp_bicubic_int.hip): LDS bytes it needs beyond the staged planes, launch.
 size_t bicubic_int_table_bytes(int tw, int th, int rows_y, int rows_uv, int hcs_y, int hcs_uv);
