@@ -359,6 +359,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_AREA_COLS_ROWS")) ctx->area_cols_rows = std::atoi(e); // 8 | 32: tile height of the column-per-lane AREA kernel (default: by tap count and launch size)
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
 }

@@ -259,7 +259,13 @@ static void sel_area(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
     // taps on -- 1080p -> 300^2 +18 %, -> 416^2 +21 % -- and is even at 2-4 taps
     if (d.area_direct == 2 && d.nkx > 3) d.area_direct = 0; // (13+ taps without the streaming kernel: generic path)
     d.area_cols = (!d.area_stream && d.area_direct == 2 && (d.area_cols_pref == 2 || (d.area_cols_pref == 1 && d.nkx >= 2))) ? 1 : 0;
-    if (d.area_cols_rows != 8 && d.area_cols_rows != 32) d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
+    if (d.area_cols_rows != 8 && d.area_cols_rows != 32) {
+        d.area_cols_rows = d.nkx >= 3 ? 8 : 32;
+        // Small outputs: 64 x 32-pixel tiles leave too few workgroups -- 1080p -> 300 x 300 is 5 x 10 tiles a frame, 3200 workgroups per 64-frame launch =
+        // 1.6 rounds of the GPU, 12 % of the tile area past the frame's edges: 8-row tiles (12160 workgroups) from 16 workgroups per CU down
+        // (profiles/r04_area_cols_rows_ab.txt; TSVPP_AREA_COLS_ROWS=8|32 forces)
+        if (d.area_cols_rows == 32 && (long)((d.dst_w + 63) / 64) * ((d.dst_h + 31) / 32) * d.n_frames < 16L * d.num_cus) d.area_cols_rows = 8;
+    }
     if (d.area_cols) { // fixed workgroup of 256 threads; tile = 16 x (rows / 2) thread tiles = 64 columns x 32 or 8 rows
         d.tx = 16;
         d.ty = d.area_cols_rows / 2;

@@ -27,6 +27,8 @@ TSVPP_SHAPE=128,2
 TSVPP_AREA_BOX=0
 TSVPP_AREA_COLS=0
 TSVPP_AREA_COLS=2
+TSVPP_AREA_COLS_ROWS=8
+TSVPP_AREA_COLS_ROWS=32
 TSVPP_AREA_DIVTAB=0
 TSVPP_AREA_STREAM=0
 TSVPP_AREA_STREAM=2
