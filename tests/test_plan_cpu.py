@@ -85,7 +85,9 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (224, 224), A, "vpp_area_stream_kernel<6,OUT>"),     # 17.1 x 9.6: 18 horizontal taps (the next instantiated count: 24), 64-column tiles
     ((3840, 2160), (128, 72), A, "vpp_area_stream_kernel<8,OUT>"),      # 30 x 30
     ((3840, 2160), (96, 54), A, "vpp_fused_gather_kernel"),              # 40 x 40: beyond 32 taps
-    ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,32"),          # 6.4 x 3.6 = 28 taps: below the streaming kernel's cross-over -> one output column per lane, taps from global memory
+    ((1920, 1080), (300, 300), A, "vpp_area_cols_kernel<2,8"),           # 6.4 x 3.6 = 28 taps: below the streaming kernel's cross-over -> one output column per lane, taps from global
+                                                                         # memory; 8-row tiles: 32-row ones would be 3200 workgroups a launch (round 4)
+    ((1920, 1080), (416, 416), A, "vpp_area_cols_kernel<2,32"),
     ((1280, 720), (1920, 1080), A, "vpp_bilinear_kernel<areaup"),  # AREA up-scale = the bilinear variant
     ((1920, 1080), (1280, 720), C, "vpp_bicubic_r32_kernel<OUT,3:2>"),  # 1.5: the streaming kernel (round 4)
     ((3840, 2160), (1920, 1080), C, "vpp_bicubic_r32_kernel<OUT,2:1>"), # 2
