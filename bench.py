@@ -760,9 +760,24 @@ def run(args):
     # Side measurements (outside the timed region, every rank takes part, same barrier / max-over-ranks bracket): the
     # headline's other three resize types (BASELINE.json's metric names none: SURVEY.md 8d "report all four") and the 4K
     # configurations C4 / C5 (north_star: "1080p and 4K ... at 1/2/4/8 GPUs").
+    def all_ranks_ok(ok):
+        """A side leg runs on every rank or on none: a rank that failed to set it up (an allocation, say) must not leave the others in a barrier."""
+        if dist is None:
+            return ok
+        import torch
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if stub else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     def side(sp, steps=20, wl_name=None):
+        w, err = None, None
         try:
             w = eng.side_work(sp)
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        if not all_ranks_ok(w is not None):
+            return {"error": err or "another rank could not set this leg up"}
+        try:
             # the device idles while rank 0 runs the oracle of the previous leg's parity check: each side leg starts with its own time-based
             # warm-up (the clock ramp, see --warmup-ms), or its 20 steps would sit on the ramp (first run of round 4: BICUBIC 0.54 instead of 0.63)
             t_w = time.perf_counter()
