@@ -237,6 +237,7 @@ struct tsvpp_ctx {
     int u8_xchg = 1;                // 16-byte stores for uint8 merged outputs through an in-wave LDS exchange
     int area_divtab = 1;            // TSVPP_AREA_DIVTAB: host-built divisor table for the float AREA kernels
     int area_cols_rows = 0;         // tile height of the column-per-lane AREA kernel: by tap count
+    int tail_shift = 1;             // TSVPP_TAIL_SHIFT: outputs 4 k + 2 columns wide end in a shifted tile column instead of a row tail and its second launch
     int area_cols = 1;              // TSVPP_AREA_COLS
     int rpt = 0;                    // TSVPP_RPT: row pairs per thread, 0 = per kernel (launch_fused)
     int dma = 1;                    // TSVPP_DMA=0 selects the register-staged path
@@ -359,6 +360,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BILINEAR_INT")) ctx->bilinear_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_DIVTAB")) ctx->area_divtab = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_COLS")) ctx->area_cols = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_TAIL_SHIFT")) ctx->tail_shift = std::atoi(e); // 0: the two-column tail launch of rounds 1-3 (A/B)
     if (const char *e = std::getenv("TSVPP_AREA_COLS_ROWS")) ctx->area_cols_rows = std::atoi(e); // 8 | 32: tile height of the column-per-lane AREA kernel (default: by tap count and launch size)
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
@@ -405,6 +407,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.lds_budget_kb = ctx->lds_kb;
     d.area_cols_pref = ctx->area_cols;
     d.area_cols_rows = ctx->area_cols_rows;
+    d.last_col0 = ctx->tail_shift ? 0 : -1; // (launch_fused decides; < 0 = not allowed)
     d.num_cus = ctx->num_cus;
     d.geo_pref = ctx->geo_pref;
     d.r32_pref = ctx->r32;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_stream_kernel(const Laun
     // a wave's tile: 128 columns x R rows (R = 4 or 8), or -- as_two == 0 -- 64 columns x 8 rows; the workgroup = 2 x 2 waves
     const bool two = d.as_two != 0;
     const int CW = two ? 128 : 64, R = two ? 4 * d.rpt : 8;
-    const int j_first = id.tx * 2 * CW + (wave & 1) * CW, i_first = id.ty * 2 * R + (wave >> 1) * R;
+    const int j_first = tile_col0(d, id.tx, 2 * CW) + (wave & 1) * CW, i_first = id.ty * 2 * R + (wave >> 1) * R;
     if (j_first >= d.dst_w || i_first >= d.dst_h) return; // (no workgroup barrier anywhere in this kernel)
     const int nrows = min(R, d.dst_h - i_first);
 

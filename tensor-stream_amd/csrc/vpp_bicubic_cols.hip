@@ -390,7 +390,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
     if (!id.valid) return;
     const int lane = (int)(threadIdx.x & 63u), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int R = 8 * d.rpt; // output rows of the tile (multiple of 8, <= 32)
-    const int j_first = id.tx * 256 + wave * 64, i_first = id.ty * R;
+    const int j_first = tile_col0(d, id.tx, 256) + wave * 64, i_first = id.ty * R;
     if (j_first >= d.dst_w) return; // (no workgroup barrier anywhere in this kernel)
     const int nrows = min(R, d.dst_h - i_first), ncrows = nrows >> 1;
     const bool dma = d.bc_dma != 0;

@@ -722,7 +722,7 @@ hipError_t launch_bilinear(bool areaup, OutKind out, const LaunchDesc &din, cons
     // only; TSVPP_GEO=2 forces the tables wherever they apply, TSVPP_GEO=0 disables them.
     const bool u8_out = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
     const bool geo_want = d.geo_pref == 2 || (d.geo_pref == 1 && u8_out && d.bil_int == 2);
-    const bool geo_ok = geo_want && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
+    const bool geo_ok = geo_want && !d.last_col0 && d.dma && (d.bil_int == 2 || d.bil_win) && (d.pitch_y & 15) == 0 && (d.pitch_uv & 15) == 0;
     if (geo_ok) {
         if (d.geo_cache) d.geo = geo_lookup(d.geo_cache, areaup, d, stream, !info || d.geo_build, d) ? 1 : 0;
         else if (info) { // tsvpp_describe: no device -- eligibility only

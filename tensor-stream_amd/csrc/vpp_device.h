@@ -825,6 +825,15 @@ __device__ __forceinline__ void convert_thread_tile(const S &s, const LaunchDesc
 // kernels 4-10 % slower although it is almost never taken), and an early exit into an inlined generic path drags that
 // path's registers into every kernel (C4's point kernel: 30 -> 110 VGPRs, 25 % slower).
 __device__ __forceinline__ bool is_row_tail(const LaunchDesc &d, int j0) { return d.dst_w - j0 < PXW; }
+// Round 4: that tail launch costs 10-50 us per step (profiles/r04_tail_probe.txt).  Wherever the output is at least one tile wide, launch_fused now
+// shifts the launch's LAST TILE COLUMN to the left so that it ends at the frame's right edge (LaunchDesc::last_col0 = dst_w - tile width, 2 mod 4):
+// every thread tile of that column then has its four columns, no row tail is left and no second launch is needed.  The columns the shifted tile shares
+// with its left neighbour are computed and stored twice with the same values; its stores start 8 bytes (fp32) / 2 bytes (uint8) off the vector
+// alignment, as every second row of such an output always did.  First column of tile `tx` of a launch whose tiles are `tile_w` columns wide:
+__device__ __forceinline__ int tile_col0(const LaunchDesc &d, int tx, int tile_w) {
+    const int j = tx * tile_w;
+    return (d.last_col0 && j + tile_w > d.dst_w) ? d.last_col0 : j; // (wave-uniform)
+}
 
 // ----------------------------------------------------------------------------------------------
 // Source footprint of a run of outputs [o0, o1] along one axis: first and last source sample any
@@ -867,7 +876,7 @@ struct Footprint {
 template <int MODE>
 __device__ __forceinline__ Footprint tile_footprint(const LaunchDesc &d, const TileId &id) {
     Footprint f;
-    f.j_first = id.tx * d.tx * PXW;
+    f.j_first = tile_col0(d, id.tx, d.tx * PXW);
     f.i_first = id.ty * d.ty * PXH * d.rpt;
     f.j_last = min(f.j_first + d.tx * PXW, d.dst_w) - 1;
     f.i_last = min(f.i_first + d.ty * PXH * d.rpt, d.dst_h) - 1;

@@ -136,6 +136,7 @@ struct LaunchDesc {
     // down-scale taps the SAME two samples per axis as BILINEAR -- only the integer weights and the final division differ.
     // 0 = off; 1 = 3 : 2 (weights (2,1) / (1,2) by index parity, sum / 9); 2 = 2 : 1 ((1,1), sum / 4).  The divisor travels as area_rcp.
     int tap22;
+    int last_col0;     // dst_w = 4 k + 2: first column of the launch's LAST tile column, shifted left so that it ends at the frame's right edge (tile_col0, vpp_device.h); 0 = no shift
     int copy16;        // no resize, Y800 / NV12 uint8 outputs: the planes are copied 16 bytes per lane (vpp_copy16_kernel), chosen by launch_fused
     GeoCache *geo_cache;
 };

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_fused_gather_kernel(const Lau
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = (id.tx * d.tx + lx) * PXW + d.col0;
+    const int j0 = (VEC ? tile_col0(d, id.tx, d.tx * PXW) : id.tx * d.tx * PXW + d.col0) + lx * PXW;
     const int i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
     if (VEC && is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_kernel(const Laun
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
+    const int j0 = tile_col0(d, id.tx, d.tx * PXW) + lx * PXW, i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
     if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_direct_float_kernel(cons
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
-    const int j0 = (id.tx * d.tx + lx) * PXW, i0 = (id.ty * d.ty + ly) * PXH;
+    const int j0 = tile_col0(d, id.tx, d.tx * PXW) + lx * PXW, i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
     if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
     __shared__ __attribute__((aligned(16))) f2 uvt[TH / 2][TW / 2];
     const TileId id = decode_tile(d);
     if (!id.valid) return;
-    const int j_first = id.tx * TW, i_first = id.ty * TH;
+    const int j_first = tile_col0(d, id.tx, TW), i_first = id.ty * TH;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t ym = (uint32_t)((uintptr_t)t.y[id.frame] & 3), uvm = (uint32_t)((uintptr_t)t.uv[id.frame] & 3);
     const uint8_t *Y = t.y[id.frame] - ym, *UV = t.uv[id.frame] - uvm; // dword-aligned bases (see load_span)
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_point_kernel(const LaunchDesc
     if (!id.valid) return;
     const int nthreads = d.tx * d.ty;
     const int tw = d.tx * PXW, th = d.ty * PXH;
-    const int j_first = id.tx * tw, i_first = id.ty * th;
+    const int j_first = tile_col0(d, id.tx, tw), i_first = id.ty * th;
     const int j_last = min(j_first + tw, d.dst_w) - 1, i_last = min(i_first + th, d.dst_h) - 1;
     const int cw = d.src_w >> 1, chh = d.src_h >> 1;
     // column extent of the tile in both planes (coordinates are monotonic in the output index)
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_color_kernel(const LaunchDesc
     const int j0 = (id.tx * d.tx + lx) * PXW;
     const int i0 = (id.ty * d.ty + ly) * PXH;
     if (j0 >= d.dst_w || i0 >= d.dst_h) return;
-    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused)
+    if (is_row_tail(d, j0)) return; // the two-column row tail belongs to the tail launch (launch_fused; no shifted tile here: the plane reads are aligned dwords)
     const uint8_t *py = t.y[id.frame] + (size_t)i0 * (size_t)d.pitch_y + (size_t)j0;
     const uint32_t yw[2] = { *(const uint32_t *)py, *(const uint32_t *)(py + d.pitch_y) };
     const uint32_t c = *(const uint32_t *)(t.uv[id.frame] + (size_t)(i0 >> 1) * (size_t)d.pitch_uv + (size_t)j0);

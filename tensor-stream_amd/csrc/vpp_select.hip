@@ -555,6 +555,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (d.area_stream) lds_bytes = S.as_lds;
     const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.copy16 ? 16 : d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
     const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : (d.r32 || d.copy16) ? d.ty * 4 : d.ty * PXH * d.rpt;
+    // dst_w = 4 k + 2: the last tile column shifted left to end at the right edge instead of a row tail and its second launch (tile_col0, vpp_device.h).
+    // Not for the colour-only kernel and the box kernel (aligned dword reads at 4-column granularity), the streaming / copy kernels (never 4 k + 2), outputs
+    // narrower than one tile; TSVPP_TAIL_SHIFT=0 (last_col0 < 0 on entry) keeps the tail launch of rounds 1-3.
+    {
+        const bool allowed = d.last_col0 >= 0;
+        d.last_col0 = 0;
+        if (allowed && vec && (d.dst_w & 3) != 0 && out < O_COUNT && mode != M_NONE && !d.area_box && !d.r32 && !d.copy16 && d.dst_w >= tile_w) d.last_col0 = d.dst_w - tile_w;
+    }
     d.tiles_x = (d.dst_w + tile_w - 1) / tile_w;
     d.tiles_y = (d.dst_h + tile_h - 1) / tile_h;
     const long total = (long)d.tiles_x * d.tiles_y * d.n_frames;
@@ -564,6 +572,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         d.blocks_per_xcd = (int)(((rows + NUM_XCD - 1) / NUM_XCD) * d.tiles_x);
     }
     if (info) {
+        info->tail = d.last_col0 > 0 ? 2 : 0; // (1: the tail launch below)
         info->tx = d.tx;
         info->ty = d.ty;
         info->rpt = d.rpt;
@@ -578,14 +587,15 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         return launch_bilinear_r32(out, d, t, stream, info);
     }
     hipError_t e = dispatch(vec, staged, d, lds_bytes, info);
-    if (e != hipSuccess || !vec || (d.dst_w & 3) == 0) return e;
-    // dst_w = 4 k + 2: the vector-store kernels left the last two columns of every row alone (is_row_tail); one more,
-    // tiny launch of the element-wise gather kernel converts them: workgroup = 1 x 64 thread tiles of 2 columns x 2 rows
+    if (e != hipSuccess || !vec || (d.dst_w & 3) == 0 || d.last_col0 > 0) return e;
+    // dst_w = 4 k + 2 without the shifted tile column: the vector-store kernels left the last two columns of every row alone (is_row_tail); one
+    // more, tiny launch of the element-wise gather kernel converts them: workgroup = 1 x 64 thread tiles of 2 columns x 2 rows
     if (info) {
         info->tail = 1;
         return e;
     }
     LaunchDesc td = d;
+    td.last_col0 = 0;
     td.col0 = d.dst_w & ~3;
     td.tx = 1;
     td.ty = 64; // one wave per workgroup: the few thousand tail threads spread over all CUs

@@ -160,7 +160,8 @@ def test_widths_4k_plus_2_stay_on_the_fast_kernels_and_unaligned_outputs_gather(
     assert plan((1920, 1080), (854, 480), A)["kernel"].startswith("vpp_area_direct_float_kernel<1")
     assert plan((1920, 1080), (1366, 768), A)["kernel"].startswith("vpp_areaf_kernel<2,2")
     p = plan((1920, 1080), (854, 480), B)
-    assert p["kernel"].startswith("vpp_bilinear_kernel<") and p["tail"] == 1   # + the two-column row-tail launch
+    assert p["kernel"].startswith("vpp_bilinear_kernel<") and p["tail"] == 2   # the last tile column shifted to the right edge: no row tail, no second launch
+    assert plan((1920, 1080), (54, 30), B)["tail"] == 1                        # narrower than one tile: + the two-column row-tail launch
     assert plan((1920, 1080), (1280, 720), B)["tail"] == 0
     assert plan((1920, 1080), (1280, 720), B, aligned_outputs=False)["kernel"] == "vpp_fused_gather_kernel<MODE,OUT,false>"
 

@@ -29,6 +29,7 @@ TSVPP_AREA_COLS=0
 TSVPP_AREA_COLS=2
 TSVPP_AREA_COLS_ROWS=8
 TSVPP_AREA_COLS_ROWS=32
+TSVPP_TAIL_SHIFT=0
 TSVPP_AREA_DIVTAB=0
 TSVPP_AREA_STREAM=0
 TSVPP_AREA_STREAM=2
