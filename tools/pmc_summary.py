@@ -13,6 +13,9 @@ if args and args[0] == "--kernel":
     kernel = args[1] or None
     args = args[2:]
 for f in args:
+    if not os.path.exists(f):  # (tools/profile.sh with QUICK=1 skips the SQ / LDS passes)
+        print(f.split('/')[-1], "not collected")
+        continue
     means, name = pmc_lib.kernel_means(pmc_lib.load(f), kernel)
     short = (name or "no tsvpp kernel").split("(")[0].replace("void ", "")
     for k, (m, n) in means.items():
