@@ -2,7 +2,7 @@
 # Runs the whole GPU parity suite once per tuning-knob setting: every alternative code path (gather fallbacks, compact vs LDS-DMA staging, the
 # BICUBIC kernels (integer / wave-per-tile with every staging mode and tile height / gathers), generic vs table vs streaming AREA kernels, thread-tile
 # heights, direct-kernel thresholds, workgroup shapes, tile orders, store policies, geometry tables, the streaming 3:2 / 2:1 kernel incl. its
-# single-pass UYVY / YUV444) must stay bit-exact.  KNOBS="..." (newline-separated) overrides the list.
+# single-pass UYVY / YUV444) must stay bit-exact.  KNOBS="..." (newline-separated) overrides the list, TESTS="files" the suite (default: tests).
 DEFAULT="TSVPP_FORCE_GATHER=1
 TSVPP_DMA=0
 TSVPP_BILINEAR_INT=0
@@ -43,5 +43,5 @@ TSVPP_GEO=0
 TSVPP_GEO=2"
 echo "${KNOBS:-$DEFAULT}" | while read -r e; do
   [ -z "$e" ] && continue
-  printf "%-55s" "$e"; timeout 200 env $e python -m pytest tests -m gpu -q --timeout 100 -p no:cacheprovider 2>&1 | tail -1
+  printf "%-55s" "$e"; timeout 200 env $e python -m pytest ${TESTS:-tests} -m gpu -q --timeout 100 -p no:cacheprovider 2>&1 | tail -1
 done
