@@ -801,8 +801,9 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const int pitch_y = in[0].pitch_y ? in[0].pitch_y : in[0].width; // reference fallback
     const int pitch_uv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
     if (pitch_y < in[0].width || pitch_uv < in[0].width) return TSVPP_ERROR;
-    // dst_w is even; when it is 4 k + 2 the vector-store kernels skip the two-column tail of every row and launch_fused adds
-    // a tiny element-wise launch for it (rows then start 8 bytes / 2 bytes off the vector alignment, which global stores tolerate).
+    // dst_w is even; when it is 4 k + 2 launch_fused shifts the launch's last tile column to the frame's right edge (or, where it cannot, the
+    // vector-store kernels skip the two-column tail of every row and a tiny element-wise launch converts it); rows then start 8 bytes / 2 bytes
+    // off the vector alignment, which global stores tolerate.
     // (alignment is decided per launch group of TSVPP_MAX_BATCH frames below: one odd pointer does not push the
     // whole batch onto the element-wise kernel)
     for (int f = 0; f < n; f++) {

@@ -15,3 +15,10 @@ bash tools/abc.sh "1920x1080:1280x720:AREA:BGR24:PLANAR:1 3840x2160:1920x1080:AR
 bash tools/pmc.sh bcr32_f32 "TSVPP_X=0" --resize BICUBIC                                                 # PMC passes of one workload (dispatched kernel only)
 # 3. every test under every knob
 bash tools/knob_matrix.sh > gpurun_out/knob_matrix.txt
+# 4. the last day: outputs 4 k + 2 columns wide (the shifted tile column against the row-tail launch), its tests under every knob
+bash tools/tail_probe.sh > gpurun_out/tail_probe3.txt
+TESTS="tests/test_gpu_tail_shift.py tests/test_gpu_geo.py" bash tools/knob_matrix.sh > gpurun_out/knob_matrix_tail.txt
+KNOBS="TSVPP_TAIL_SHIFT=0
+TSVPP_FORCE_GATHER=1
+TSVPP_DMA=0" bash tools/knob_matrix.sh > gpurun_out/knob_matrix_tail2.txt
+#    (blocks 1 was run again afterwards with QUICK unset: every kernel's tile origin changed, so every PMC entry was re-taken)
