@@ -158,7 +158,9 @@ int tsvpp_area_pattern(float scale, float *out, int max_floats, int *taps);
  * src/VideoProcessor.cpp:106-151) plus this library's kernel / workgroup-shape / LDS choice -- as one line of
  * key=value text, e.g. "mode=bilinear out=f32_planar ... kernel=vpp_bilinear_kernel<...> shape=32x8 rpt=2 ...".
  * Needs no context and no GPU (host logic only; TSVPP_* knobs are honoured).  `aligned_outputs`: outputs are 16-byte
- * aligned.  Returns TSVPP_OK or the status tsvpp_convert would return for the request. */
+ * aligned.  tail= says how an output 4 k + 2 columns wide ends its rows: 2 = the launch's last tile column is shifted to the
+ * frame's right edge (one launch), 1 = a second, element-wise launch converts the two-column row tail, 0 = neither is needed.
+ * Returns TSVPP_OK or the status tsvpp_convert would return for the request. */
 int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch_y, int pitch_uv, int n_frames, int aligned_outputs, char *buf,
                    size_t buf_len);
 
