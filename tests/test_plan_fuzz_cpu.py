@@ -40,6 +40,7 @@ def random_request(rng):
 def test_every_request_gets_a_launchable_plan_or_a_reference_status(chunk):
     rng = np.random.default_rng(555 + chunk)
     kernels = set()
+    tails = {1: 0, 2: 0}
     for _ in range(400):
         r = random_request(rng)
         fp = ts.FrameParameters(width=r["dst"][0], height=r["dst"][1], crop_coords=r["crop"], resize_type=r["rt"], pixel_format=r["fourcc"],
@@ -58,5 +59,17 @@ def test_every_request_gets_a_launchable_plan_or_a_reference_status(chunk):
         tw, th = (int(v) for v in p["tiles"].split("x"))
         assert tw >= 1 and th >= 1, (r, p)
         kernels.add(p["kernel"].split("<")[0])
+        # how a row ends (include/tsvpp.h): only outputs 4 k + 2 columns wide on vector-store kernels need anything; a shifted tile column (2) only where a
+        # kernel with its own resize takes the request and the output is at least two tiles wide; never for the box / colour / streaming / copy kernels
+        dw = r["dst"][0] or (r["crop"][2] - r["crop"][0] or r["w"])
+        vec = r["aligned"] or r["fourcc"] in (4, 5)   # (UYVY / YUV444: the first pass writes the library's own, aligned scratch frames)
+        if dw % 4 == 0 or not vec:
+            assert p["tail"] == 0, (r, p)
+        else:
+            assert p["tail"] in (1, 2), (r, p)
+            if p["tail"] == 2:
+                assert tw >= 2 and not any(k in p["kernel"] for k in ("area_box", "color", "r32", "copy16")), (r, p)
+            tails[p["tail"]] += 1
+    assert tails[1] > 0 and tails[2] > 0, tails
     # the sweep reaches every kernel family of the fused launch
     assert {"vpp_bilinear_kernel", "vpp_bilinear_r32_kernel", "vpp_area_box_kernel", "vpp_point_kernel", "vpp_color_kernel"} <= kernels, kernels
