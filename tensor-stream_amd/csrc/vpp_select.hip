@@ -161,12 +161,8 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
 
 // 4. candidate workgroup shapes
 static void sel_shapes(Mode mode, OutKind out, LaunchDesc &d, FusedSel &S) {
-    bool &staged = S.staged;
-    size_t &lds_bytes = S.lds_bytes;
     int (&shapes)[5][2] = S.shapes;
-    const size_t kLdsBudget = S.lds_budget;
     const bool f32_out = S.f32_out, two_tap = S.two_tap;
-    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     // Candidate workgroup shapes, largest first; the staged kernels take the first whose source
     // footprint fits the LDS budget (several workgroups per CU must stay resident to overlap one
     // group's loads with another's arithmetic).
@@ -278,8 +274,6 @@ static void sel_point(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
     size_t &lds_bytes = S.lds_bytes;
     int (&shapes)[5][2] = S.shapes;
     const size_t kLdsBudget = S.lds_budget;
-    const bool f32_out = S.f32_out, two_tap = S.two_tap;
-    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     const bool point = d.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
     if (!point) d.point_kind = PK_NONE;
     if (point && vec && !d.force_gather) {
@@ -317,7 +311,6 @@ static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gat
     int (&shapes)[5][2] = S.shapes;
     const size_t kLdsBudget = S.lds_budget;
     const bool f32_out = S.f32_out, two_tap = S.two_tap;
-    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     auto workgroups = [&](const int *sh, int rpt) { return fused_workgroups(d, sh, rpt); };
     if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
         const int want_dma = d.dma;
@@ -433,10 +426,6 @@ static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gat
 static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, FusedSel &S, hipStream_t stream, LaunchInfo *info) {
     bool &staged = S.staged;
     size_t &lds_bytes = S.lds_bytes;
-    int (&shapes)[5][2] = S.shapes;
-    const size_t kLdsBudget = S.lds_budget;
-    const bool f32_out = S.f32_out, two_tap = S.two_tap;
-    (void)staged; (void)lds_bytes; (void)shapes; (void)kLdsBudget; (void)f32_out; (void)two_tap;
     // BICUBIC that the integer kernel above did not take (non-dyadic weights -- or TSVPP_BICUBIC_COLS=2: every request): one wave per
     // 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane (vpp_bicubic_cols.hip).  A taller
     // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
