@@ -337,6 +337,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--alias", type=int, default=0, help="DIAGNOSTIC (not a measurement of the path): bit 0 = all frames of a launch read one "
                     "input frame, bit 1 = all write one output buffer, so that reads / writes stay in cache; separates issue-bound from memory-bound kernels")
+    ap.add_argument("--streams", type=int, default=1, help="DIAGNOSTIC (not the bench line's measurement): issue the steps of a timed region round-robin on N HIP streams -- "
+                    "independent batches of N consumers: one launch's drain overlaps the next one's fill; avg_launch_ms is then wall time per launch, not a launch's duration")
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets")
     ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
@@ -532,6 +534,7 @@ class GpuEngine:
         self.parity = "skipped"  # filled in by check_parity() AFTER the timed region, on the timed launches' own output
 
         self.cur_stream = torch.cuda.current_stream(dev).cuda_stream
+        self.extra_streams = [torch.cuda.Stream() for _ in range(max(0, getattr(args, "streams", 1) - 1))]  # --streams N (diagnostic)
         self.graphs = []
         if args.graph:  # one graph per buffer set, captured on a side stream, replayed on the current one
             side = torch.cuda.Stream()
@@ -582,7 +585,18 @@ class GpuEngine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        if work is None:
+        if self.extra_streams and work is None:  # --streams N: step k on stream k mod N, all forked from / joined into the current stream
+            n = len(self.extra_streams) + 1
+            for st in self.extra_streams:
+                st.wait_event(ev0)
+            for i in range(steps):
+                k = (first + i) % n
+                self.work.issue(first + i, self.cur_stream if k == 0 else self.extra_streams[k - 1].cuda_stream)
+            for st in self.extra_streams:
+                e = torch.cuda.Event()
+                e.record(st)
+                torch.cuda.current_stream().wait_event(e)
+        elif work is None:
             for i in range(steps):
                 self.step(first + i)
         else:
@@ -856,6 +870,8 @@ def run(args):
             res["config"]["coeff_broadcast"] = eng.coeff_broadcast
         if args.alias:  # not a measurement of the path: the frames of a launch share buffers
             res["data"] = "DIAGNOSTIC: aliased buffers (--alias %d)" % args.alias
+        if args.streams > 1:  # not the contract's measurement: launches of several streams overlap, avg_launch_ms / roofline are wall time per launch
+            res["data"] = "DIAGNOSTIC: steps issued round-robin on %d streams (--streams): roofline figures are per launch of WALL time, not launch durations" % args.streams
         rf = res["roofline"]
         rf["write_bytes_per_frame"] = write_bytes_per_frame
         tb = None

@@ -83,6 +83,16 @@ def test_main_flow_on_the_stub_engine(flags, capsys, monkeypatch):
         assert res["metric"] == bench.METRIC
 
 
+def test_streams_flag_marks_the_line_as_a_diagnostic(capsys, monkeypatch):
+    """--streams N overlaps launches: its figures are wall time per launch, so the line must say that it is not the contract's measurement."""
+    monkeypatch.setenv("TSVPP_BENCH_STUB", "1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.main(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-others", "--streams", "2"]) == 0
+    res = _line(capsys.readouterr().out)
+    assert res["data"].startswith("DIAGNOSTIC") and "2 streams" in res["data"]
+
+
 def test_a_failing_side_leg_cannot_swallow_the_line(capsys, monkeypatch):
     monkeypatch.setenv("TSVPP_BENCH_STUB", "1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
