@@ -254,7 +254,7 @@ def latency_leg(spec, iters=2000):
 
 
 _SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
-_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear_up2", "vpp_bilinear_up2.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_up2", "vpp_bicubic_up2.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
+_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear_up2", "vpp_bilinear_up2.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
                  ("vpp_bicubic_cols", "vpp_bicubic_cols.hip"), ("vpp_area_box", "vpp_area_box.hip"), ("vpp_area_stream", "vpp_area_stream.hip"),
                  ("fmt_", "vpp_formats.hip")]
 
@@ -267,8 +267,7 @@ def kernel_source_files(kernel=None):
     k = kernel.split("::")[-1]
     unit = next((f for prefix, f in _KERNEL_FILES if k.startswith(prefix)), "vpp_kernels.hip")
     extra = {"vpp_bicubic_r32.hip": ["vpp_bicubic_r32_core.h", "vpp_r32_store.h"], "vpp_bilinear_r32.hip": ["vpp_r32_store.h"],
-             "vpp_bilinear_up2.hip": ["vpp_bilinear_up2_core.h", "vpp_bicubic_r32_core.h", "vpp_r32_store.h", "vpp_up2.h"],
-             "vpp_bicubic_up2.hip": ["vpp_bicubic_up2_core.h", "vpp_bilinear_up2_core.h", "vpp_bicubic_r32_core.h", "vpp_r32_store.h", "vpp_up2.h"]}.get(unit, [])
+             "vpp_bilinear_up2.hip": ["vpp_bilinear_up2_core.h", "vpp_bicubic_r32_core.h", "vpp_r32_store.h", "vpp_up2.h"]}.get(unit, [])
     return ["tensor-stream_amd/csrc/" + f for f in [unit] + extra] + _SHARED_SOURCES
 
 

@@ -43,7 +43,6 @@ static const StreamRow kStreamRows[] = {
     { M_NEAREST, 4, 6, "profiles/r02_r32_ab.txt: NEAREST merged 0.83 -> 0.99" },
     { M_BICUBIC, 3, 7, "profiles/r04_bicubic_r32_ab.txt: 1080p -> 720p fp32 planar 0.670 -> 0.711, uint8 merged 0.362 -> 0.548, fp32 merged 0.573 -> 0.702" },
     { M_BICUBIC, 4, 8, "profiles/r04_bicubic_r32_ab.txt: 4K -> 1080p fp32 planar 0.652 -> 0.730, uint8 merged 0.368 -> 0.631; 1080p -> 540p 0.619 -> 0.691" },
-    { M_BICUBIC, 1, 9, "profiles/r04_up2_ab.txt (vpp_bicubic_up2.hip): uint8 outputs of the 1 : 2 up-scale, 0.31 on the LDS integer kernel (r04_upscale_u8_probe.txt)" },
     { M_BILINEAR, 1, 10, "profiles/r04_up2_ab.txt (vpp_bilinear_up2.hip): uint8 outputs of the 1 : 2 up-scale, 0.34 on the LDS kernel (r04_upscale_u8_probe.txt)" },
 };
 // The streaming kernel instance of this request, or 0.  `mode` is the mode the launch runs as (an AREA request that took the 2x2-tap integer tile,
@@ -59,8 +58,6 @@ static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d) 
     for (const StreamRow &row : kStreamRows)
         if (row.mode == mode && row.p2 == p2) r32 = row.r32;
     if (!r32) return 0;
-    if (r32 == 9) // BICUBIC 1 : 2: uint8 outputs (fp32 planar runs 0.81 on the LDS integer kernel: output-bound there already; TSVPP_R32=2 takes fp32 too)
-        return (d.w_dyadic && d.bicubic_int_pref == 1 && d.bicubic_cols_pref != 2 && d.r32_pref && out < O_COUNT && (u8_flavour || (f32_out && d.r32_pref == 2))) ? r32 : 0;
     if (r32 == 7 || r32 == 8) // BICUBIC: every flavour of the colour back end (TSVPP_BICUBIC_INT=2 keeps the LDS integer kernel, TSVPP_BICUBIC_COLS=2 the column kernel)
         return (d.w_dyadic && d.bicubic_int_pref == 1 && d.bicubic_cols_pref != 2 && out < O_COUNT) ? r32 : 0;
     // 2x2-tap kinds: uint8 flavours; fp32 flavours (round 4, through the shared output side vpp_r32_store.h) tie or lose against the LDS kernels for RGB / BGR
@@ -85,7 +82,7 @@ static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int
     auto waste = [&](int w) { return (double)((n + w - 1) / w * w) / (double)n - 1.0; };
     tx = 64;
     ty = 4;
-    if (r32 == 9 || r32 == 10) return; // the 1 : 2 up-scales: 64 x 4 threads (neighbour dwords by wave shuffle; not swept yet)
+    if (r32 == 10) return; // the 1 : 2 up-scale: 64 x 4 threads (neighbour dwords by wave shuffle; not swept yet)
     if (r32 < 7) {
         if (f32_out) ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
         // YUV444, the one VALU-bound flavour of the 2x2-tap kinds (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280 columns = 2.5
@@ -520,7 +517,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     const float ratio_area = d.xr * d.yr;
     // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
     const int stream_r32 = stream_select(mode, out, vec, d);
-    const int bc_r32 = (stream_r32 >= 7 && stream_r32 <= 9) ? stream_r32 : 0;
+    const int bc_r32 = (stream_r32 == 7 || stream_r32 == 8) ? stream_r32 : 0;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
@@ -584,8 +581,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         if (!d.r32) return hipErrorNotSupported;
         return launch_bilinear_r32(out, d, t, stream, info);
     }
-    if (d.r32 == 10) return launch_bilinear_up2(out, d, t, stream, info); // (their launchers are not vpp_kernels.hip's business: vpp_up2.h)
-    if (d.r32 == 9) return launch_bicubic_up2(out, d, t, stream, info);
+    if (d.r32 == 10) return launch_bilinear_up2(out, d, t, stream, info); // (its launcher is not vpp_kernels.hip's business: vpp_up2.h)
     hipError_t e = dispatch(vec, staged, d, lds_bytes, info);
     if (e != hipSuccess || !vec || (d.dst_w & 3) == 0 || d.last_col0 > 0) return e;
     // dst_w = 4 k + 2 without the shifted tile column: the vector-store kernels left the last two columns of every row alone (is_row_tail); one

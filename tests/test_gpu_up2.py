@@ -1,9 +1,8 @@
-"""GPU: the streaming kernels for the BILINEAR and BICUBIC up-scales at exactly 1 : 2 with uint8 outputs (vpp_bilinear_up2_kernel,
-vpp_bicubic_up2_kernel: sums as v_dot4 on the source dwords, neighbour dwords by wave shuffle, the 8 x 4-pixel output side of the streaming kernels)
-against the oracle, bit for bit: every flavour they take, one-lane and partial runs, the narrow (three loads per row) and the wide (shuffles)
-workgroups, frame edges (BICUBIC: the first output of an axis is the first sample, the last three collapse their taps), one / two / many tile rows,
-crops, batches, the two-pass formats' first pass; requests they cannot take keep their kernels.  The thread-tile arithmetic itself is also checked on
-the CPU (tests/test_bilinear_up2_cpu.py, tests/test_bicubic_up2_cpu.py)."""
+"""GPU: the streaming kernel for the BILINEAR up-scale at exactly 1 : 2 with uint8 outputs (vpp_bilinear_up2_kernel: horizontal pair sums as v_dot4 on
+the source dwords, neighbour dwords by wave shuffle, the 8 x 4-pixel output side of the streaming kernels) against the oracle, bit for bit: every
+flavour it takes, one-lane and partial runs, the narrow (three loads per row) and the wide (shuffles) workgroups, frame edges, crops, batches, the
+two-pass formats' first pass; requests it cannot take keep their kernels.  The thread-tile arithmetic itself is also checked on the CPU
+(tests/test_bilinear_up2_cpu.py)."""
 import os
 
 import numpy as np
@@ -25,7 +24,7 @@ def check(vpp, oracle, y, uv, w, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0), n=1,
     fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
     if not KNOBS or knob_ctx:
         k = ts.describe(fp, w, y.shape[0], pitch=y.shape[1], n_frames=n)["kernel"]
-        assert k.startswith("vpp_bicubic_up2_kernel" if rt == BICUBIC else "vpp_bilinear_up2_kernel") == up2, (k, w, y.shape, dst, crop, fourcc, norm, rt)
+        assert k.startswith("vpp_bilinear_up2_kernel") == up2, (k, w, y.shape, dst, crop, fourcc, norm)
     ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
     got = vpp.Convert(ty, tuv, fp, width=w) if n == 1 else vpp.convert_batch([ty] * n, [tuv] * n, fp, width=w)
     torch.cuda.synchronize()
@@ -43,44 +42,42 @@ def check(vpp, oracle, y, uv, w, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0), n=1,
                                        ((260, 20), 260),    # 65 threads: a full wave + a run of ONE lane (its own first and last)
                                        ((516, 10), 516)])   # 129 threads: two full waves + one lane
 @pytest.mark.parametrize("fourcc,planes", [(RGB24, 0), (BGR24, 1), (RGB24, 1), (NV12, 1), (Y800, 1)])
-@pytest.mark.parametrize("rt", [BILINEAR, BICUBIC])
-def test_sizes_and_flavours(vpp, oracle, src, pitch, fourcc, planes, rt):
+def test_sizes_and_flavours(vpp, oracle, src, pitch, fourcc, planes):
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + fourcc + planes, pitch=pitch)
-    check(vpp, oracle, y, uv, src[0], fourcc=fourcc, planes=planes, rt=rt)
+    check(vpp, oracle, y, uv, src[0], fourcc=fourcc, planes=planes)
 
 
-@pytest.mark.parametrize("rt", [BILINEAR, BICUBIC])
-def test_batches_crops_two_pass_fallbacks(vpp, oracle, rt):
+def test_batches_crops_two_pass_fallbacks(vpp, oracle):
     y, uv = synth_nv12(960, 540, seed=31, pitch=1024)
-    check(vpp, oracle, y, uv, 960, rt=rt, fourcc=BGR24, planes=1, n=64)
-    check(vpp, oracle, y, uv, 960, rt=rt, fourcc=RGB24, planes=0, n=3)
-    check(vpp, oracle, y, uv, 960, rt=rt, crop=(4, 2, 484, 272))                        # origin a multiple of 4: pointers stay dword-aligned
-    check(vpp, oracle, y, uv, 960, rt=rt, crop=(8, 7, 488, 277), planes=1)
-    check(vpp, oracle, y, uv, 960, rt=rt, crop=(6, 2, 486, 272), up2=False)             # misaligned origin: the LDS kernel
-    check(vpp, oracle, y, uv, 960, rt=rt, crop=(5, 3, 485, 273), planes=1, up2=False)   # odd origin (U / V swapped)
-    check(vpp, oracle, y, uv, 960, rt=rt, norm=True, up2=False)                         # fp32 outputs stay on the LDS kernels (output-bound there already)
-    check(vpp, oracle, y, uv, 960, rt=rt, fourcc=HSV, planes=1, norm=True, up2=False)
-    for other in (NEAREST, AREA):                                                # the other interpolations keep their kernels
-        check(vpp, oracle, y, uv, 960, rt=other, up2=False)
+    check(vpp, oracle, y, uv, 960, fourcc=BGR24, planes=1, n=64)
+    check(vpp, oracle, y, uv, 960, fourcc=RGB24, planes=0, n=3)
+    check(vpp, oracle, y, uv, 960, crop=(4, 2, 484, 272))                        # origin a multiple of 4: pointers stay dword-aligned
+    check(vpp, oracle, y, uv, 960, crop=(8, 7, 488, 277), planes=1)
+    check(vpp, oracle, y, uv, 960, crop=(6, 2, 486, 272), up2=False)             # misaligned origin: the LDS kernel
+    check(vpp, oracle, y, uv, 960, crop=(5, 3, 485, 273), planes=1, up2=False)   # odd origin (U / V swapped)
+    check(vpp, oracle, y, uv, 960, norm=True, up2=False)                         # fp32 outputs stay on vpp_bilinear_kernel (output-bound there already)
+    check(vpp, oracle, y, uv, 960, fourcc=HSV, planes=1, norm=True, up2=False)
+    for rt in (NEAREST, BICUBIC, AREA):                                          # the other interpolations keep their kernels
+        check(vpp, oracle, y, uv, 960, rt=rt, up2=False)
     for fcc in (UYVY, YUV444):                                                   # pass 1 of the two-pass formats writes NV12 with this kernel
-        check(vpp, oracle, y, uv, 960, rt=rt, fourcc=fcc, planes=1)
-        check(vpp, oracle, y, uv, 960, rt=rt, fourcc=fcc, planes=1, norm=True)
+        check(vpp, oracle, y, uv, 960, fourcc=fcc, planes=1)
+        check(vpp, oracle, y, uv, 960, fourcc=fcc, planes=1, norm=True)
     y, uv = synth_nv12(962, 540, seed=32, pitch=964)
-    check(vpp, oracle, y, uv, 962, rt=rt, up2=False)                                    # 1924 columns = 8 k + 4
+    check(vpp, oracle, y, uv, 962, up2=False)                                    # 1924 columns = 8 k + 4
     y, uv = synth_nv12(960, 542, seed=33)
-    check(vpp, oracle, y, uv, 960, rt=rt)                                               # 271 row quads: a partial last tile row
+    check(vpp, oracle, y, uv, 960)                                               # 271 row quads: a partial last tile row
     y, uv = synth_nv12(960, 540, seed=34, pitch=962)
-    check(vpp, oracle, y, uv, 960, rt=rt, up2=False)                                    # pitch not a multiple of 4
+    check(vpp, oracle, y, uv, 960, up2=False)                                    # pitch not a multiple of 4
     for val in (0, 255):                                                         # saturated planes: every sum at its extreme
         yy = np.full((36, 96), val, np.uint8)
         uu = np.full((18, 96), 255 - val, np.uint8)
-        check(vpp, oracle, yy, uu, 96, rt=rt, planes=1)
-        check(vpp, oracle, yy, uu, 96, rt=rt, planes=0)
+        check(vpp, oracle, yy, uu, 96, planes=1)
+        check(vpp, oracle, yy, uu, 96, planes=0)
     yy = (np.indices((36, 96)).sum(0) % 2 * 255).astype(np.uint8)                # checkerboard + hard frame edges
     uu = (np.indices((18, 96))[1] // 2 % 2 * 255).astype(np.uint8)
     yy[:, :1], yy[:, -1:], yy[:1], yy[-1:] = 255, 0, 0, 255
-    check(vpp, oracle, yy, uu, 96, rt=rt, planes=1)
-    check(vpp, oracle, yy, uu, 96, rt=rt, fourcc=NV12, planes=1)
+    check(vpp, oracle, yy, uu, 96, planes=1)
+    check(vpp, oracle, yy, uu, 96, fourcc=NV12, planes=1)
 
 
 @pytest.mark.parametrize("knobs", [{"TSVPP_R32": "2"}, {"TSVPP_R32": "2", "TSVPP_SHAPE": "32,8"}, {"TSVPP_SHAPE": "16,4"}, {"TSVPP_SHAPE": "128,2"}])
@@ -93,12 +90,11 @@ def test_fp32_flavours_and_other_workgroup_shapes(oracle, knobs, monkeypatch):
     try:
         for src, pitch in (((960, 540), 960), ((260, 20), 260), ((24, 12), 24)):
             y, uv = synth_nv12(src[0], src[1], seed=src[0] + len(knobs), pitch=pitch)
-            for rt in (BILINEAR, BICUBIC):
-                check(v, oracle, y, uv, src[0], fourcc=RGB24, planes=1, knob_ctx=True, rt=rt)
-                check(v, oracle, y, uv, src[0], fourcc=BGR24, planes=0, knob_ctx=True, rt=rt)
-                if knobs.get("TSVPP_R32") == "2":
-                    for fourcc, planes in ((BGR24, 0), (RGB24, 1), (NV12, 1), (Y800, 1), (HSV, 1)):
-                        check(v, oracle, y, uv, src[0], fourcc=fourcc, planes=planes, norm=True, knob_ctx=True, rt=rt)
+            check(v, oracle, y, uv, src[0], fourcc=RGB24, planes=1, knob_ctx=True)
+            check(v, oracle, y, uv, src[0], fourcc=BGR24, planes=0, knob_ctx=True)
+            if knobs.get("TSVPP_R32") == "2":
+                for fourcc, planes in ((BGR24, 0), (RGB24, 1), (NV12, 1), (Y800, 1), (HSV, 1)):
+                    check(v, oracle, y, uv, src[0], fourcc=fourcc, planes=planes, norm=True, knob_ctx=True)
     finally:
         v.Close()
 
@@ -110,6 +106,5 @@ def test_r32_off_keeps_the_lds_kernel(oracle, monkeypatch):
     try:
         y, uv = synth_nv12(960, 540, seed=5)
         check(v, oracle, y, uv, 960, planes=1, up2=False, knob_ctx=True)
-        check(v, oracle, y, uv, 960, planes=1, up2=False, knob_ctx=True, rt=BICUBIC)
     finally:
         v.Close()
