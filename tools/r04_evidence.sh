@@ -22,3 +22,7 @@ KNOBS="TSVPP_TAIL_SHIFT=0
 TSVPP_FORCE_GATHER=1
 TSVPP_DMA=0" bash tools/knob_matrix.sh > gpurun_out/knob_matrix_tail2.txt
 #    (blocks 1 was run again afterwards with QUICK unset: every kernel's tile origin changed, so every PMC entry was re-taken)
+# 5. the last hours: launches on several streams (diagnostic), up-scales with uint8 outputs before / after the streaming BILINEAR 1 : 2 kernel, its BICUBIC twin (commit ed4f57e)
+bash tools/streams_probe.sh > gpurun_out/streams_probe.txt
+bash tools/abc.sh "960x540:1920x1080:BILINEAR:RGB24:MERGED:0 960x540:1920x1080:BILINEAR:RGB24:PLANAR:0 1920x1080:3840x2160:BILINEAR:RGB24:MERGED:0" "TSVPP_R32=0" "TSVPP_X=0" > gpurun_out/up2_ab.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/r04_gpu_suite.txt   # 1143 passed: the state of the final commit
