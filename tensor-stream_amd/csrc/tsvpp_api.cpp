@@ -248,6 +248,8 @@ struct tsvpp_ctx {
     int area_stream_min_taps = 40;  // ... from this many taps (rx * ry) per value on (measured cross-over)
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
+    int bilinear_rows = 1;          // TSVPP_BILINEAR_ROWS: BILINEAR at sparse ratios with the tapped rows as LDS-DMA row segments (vpp_bilinear_rows.hip; 1: ratio product >= 12, 2: wherever it applies, 0: byte gathers)
+    int bilinear_rows_waves = 0;    // TSVPP_BILINEAR_ROWS_WAVES: its waves per workgroup (1 / 2 / 4; 0 = automatic)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
     GeoCache *geo = nullptr;        // ... their device copies, one set per (request geometry, tile shape)
     std::mutex area_mu;
@@ -353,6 +355,8 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_DIRECT_MIN")) ctx->area_direct_min = (float)std::atof(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS")) ctx->bilinear_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS_WAVES")) ctx->bilinear_rows_waves = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_STREAM")) ctx->area_stream = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_DMA")) ctx->bicubic_dma = std::atoi(e);
@@ -411,6 +415,8 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.num_cus = ctx->num_cus;
     d.geo_pref = ctx->geo_pref;
     d.r32_pref = ctx->r32;
+    d.bil_rows_pref = ctx->bilinear_rows;
+    d.br_waves = ctx->bilinear_rows_waves; // (forced; launch_fused chooses)
     d.geo_cache = ctx->geo;
 }
 

@@ -138,6 +138,10 @@ struct LaunchDesc {
     int tap22;
     int last_col0;     // dst_w = 4 k + 2: first column of the launch's LAST tile column, shifted left so that it ends at the frame's right edge (tile_col0, vpp_device.h); 0 = no shift
     int copy16;        // no resize, Y800 / NV12 uint8 outputs: the planes are copied 16 bytes per lane (vpp_copy16_kernel), chosen by launch_fused
+    // BILINEAR at sparse ratios, one wave per 64-column tile, the TAPPED rows staged as LDS-DMA row segments (vpp_bilinear_rows.hip): allowed (TSVPP_BILINEAR_ROWS: 1 = where the
+    // byte-gather kernel ran until round 4 -- ratio product >= 12 --, 2 = wherever a segment fits one DMA instruction, 0 = never) / chosen by launch_fused: the 16-byte chunks of one
+    // row segment (<= 64), 0 = off; br_waves: waves (64-column tiles) per workgroup; br_rpi: segments per DMA instruction (64 / bil_rows).  A wave's LDS bytes travel in bc_wave_bytes.
+    int bil_rows_pref, bil_rows, br_waves, br_rpi;
     GeoCache *geo_cache;
 };
 
@@ -230,6 +234,9 @@ hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t
 
 // BICUBIC at exactly 3 : 2 / 2 : 1 on both axes, every output flavour, straight from global memory (vpp_bicubic_r32.hip; d.r32 = 7 / 8).
 hipError_t launch_bicubic_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
+
+// BILINEAR at sparse ratios: the tapped rows as LDS-DMA row segments, one wave per tile (vpp_bilinear_rows.hip; d.bil_rows).
+hipError_t launch_bilinear_rows(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);
 
 // BILINEAR at exactly 3 : 2 on both axes, uint8 outputs, straight from global memory (vpp_bilinear_r32.hip).
 hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);

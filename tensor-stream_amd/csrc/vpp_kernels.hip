@@ -947,6 +947,9 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_DOWN || MODE == M_NEAREST) {
         if (d.r32 >= 1 && d.r32 <= 6) return launch_bilinear_r32((OutKind)OUT, d, t, stream, info);
     }
+    if constexpr (MODE == M_BILINEAR) {
+        if (d.bil_rows) return launch_bilinear_rows((OutKind)OUT, d, t, lds_bytes, stream, info);
+    }
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_UP) {
         if (staged) {
             return launch_bilinear(MODE == M_AREA_UP, (OutKind)OUT, d, t, grid.x, lds_bytes, stream, info);

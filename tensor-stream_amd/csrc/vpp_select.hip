@@ -108,7 +108,7 @@ static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int
 // launch_fused calls them in order (tests/golden/describe_snapshot.json pins the outcome for 417 requests).
 struct FusedSel {
     int shapes[5][2] = { { 32, 8 }, { 32, 4 }, { 16, 4 }, { 0, 0 }, { 0, 0 } }; // candidate workgroup shapes, largest first
-    size_t lds_budget = 40 * 1024, lds_bytes = 0, as_lds = 0;
+    size_t lds_budget = 40 * 1024, lds_bytes = 0, as_lds = 0, br_lds = 0;
     bool staged = false, f32_out = false, two_tap = false;
 };
 static long fused_workgroups(const LaunchDesc &d, const int *sh, int rpt) {
@@ -310,6 +310,47 @@ static void sel_point(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
     }
 }
 
+// 6b. BILINEAR at sparse ratios: the tapped rows as LDS-DMA row segments, one wave per 64-column tile (vpp_bilinear_rows.hip)
+static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int stream_r32, LaunchDesc &d, FusedSel &S) {
+    // Until round 4 every BILINEAR request with a ratio product >= 12 ran on the byte-gather kernel (BASELINE config C3: 5.0 x 2.8125).  That kernel is bound by the
+    // issue of its gathers -- 64 lanes = 64 cache lines per load instruction -- not by the launch ramp: 64 -> 128 frames took C3 from 23.2 to 50.1 us
+    // (profiles/r04_batch128_ab.txt).  Here the tapped rows arrive as contiguous 16-byte chunks.  Needs pitches that are multiples of 16 (every row of a plane then has
+    // the same misalignment) and a row segment of at most 64 chunks = ONE DMA instruction (horizontal ratios up to ~15.7).  TSVPP_BILINEAR_ROWS=2 takes every
+    // BILINEAR request that satisfies those two (tests: ratios the LDS-staged kernel serves by default), 0 keeps the gathers.
+    d.bil_rows = 0;
+    if (mode != M_BILINEAR || d.tap22 || S.staged || !vec || d.force_gather || !d.bil_rows_pref || stream_r32) return;
+    if (!(sparse_gather || d.bil_rows_pref == 2)) return;
+    if ((d.pitch_y & 15) != 0 || (d.pitch_uv & 15) != 0) return;
+    // bytes a tile's 64 luma columns / 32 chroma pair columns span (+ the right-hand tap, + 1 for the float coordinate), + up to 15 bytes of misalignment, in chunks
+    const int span_y = (int)(63.0 * (double)d.xr) + 3, span_c = 2 * ((int)(31.0 * (double)d.xr) + 3);
+    const int L = ((span_y > span_c ? span_y : span_c) + 30) / 16;
+    if (L > 64) return;
+    const int rpt = (d.rpt_pref >= 1 && d.rpt_pref <= 4) ? d.rpt_pref : 1; // tile height 8 rows: the most waves in flight (TSVPP_RPT: 16 / 24 / 32)
+    const int wave_bytes = 3 * 8 * rpt * 16 * L + 64;
+    // waves (64-column tiles) per workgroup: the largest of 4 / 2 / 1 that launches no more waves than the narrowest choice (300 columns: five single-wave workgroups
+    // instead of two four-wave ones, three of whose waves would exit at once) within 48 KiB of LDS
+    int nw = 0;
+    long best = 0;
+    for (int w = 4; w >= 1; w >>= 1) {
+        if ((long)w * wave_bytes > 48 * 1024) continue;
+        if (d.br_waves && d.br_waves != w) continue; // TSVPP_BILINEAR_ROWS_WAVES (A/B)
+        const long waves = (long)((d.dst_w + 64 * w - 1) / (64 * w)) * w;
+        if (!nw || waves < best) {
+            nw = w;
+            best = waves;
+        }
+    }
+    if (!nw) return;
+    d.bil_rows = L;
+    d.br_rpi = 64 / L;
+    d.br_waves = nw;
+    d.bc_wave_bytes = wave_bytes;
+    S.br_lds = (size_t)nw * wave_bytes;
+    d.tx = 16; // colour phase: a wave = 16 x 4 thread tiles per 8-row slab (MergedRun: runs of 16 lanes)
+    d.ty = 4;
+    d.rpt = rpt;
+}
+
 // 7. the LDS-staged kernels (2x2-tap, integer BICUBIC, dyadic / small float AREA): first workgroup shape, rows per thread and staging layout that fit
 static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gather, LaunchDesc &d, FusedSel &S) {
     bool &staged = S.staged;
@@ -318,7 +359,7 @@ static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gat
     const size_t kLdsBudget = S.lds_budget;
     const bool f32_out = S.f32_out, two_tap = S.two_tap;
     auto workgroups = [&](const int *sh, int rpt) { return fused_workgroups(d, sh, rpt); };
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream) {
+    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream && !d.bil_rows) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
@@ -521,6 +562,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
+    sel_bilinear_rows(mode, vec, sparse_gather, stream_r32, d, S);
     sel_staged(mode, vec, bicubic_staged, sparse_gather, d, S);
     if (!staged) d.dma = 0;
     sel_bicubic_cols(mode, vec, bc_r32, d, S, stream, info);
@@ -548,8 +590,9 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     if (d.bicubic_cols) lds_bytes = bc_lds;
     if (d.r32) d.area_stream = 0;
     if (d.area_stream) lds_bytes = S.as_lds;
-    const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.tx * (d.copy16 ? 16 : d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves
-    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : d.bicubic_cols ? 8 * d.rpt : (d.r32 || d.copy16) ? d.ty * 4 : d.ty * PXH * d.rpt;
+    if (d.bil_rows) lds_bytes = S.br_lds;
+    const int tile_w = d.area_stream ? (d.as_two ? 256 : 128) : d.bicubic_cols ? 256 : d.bil_rows ? 64 * d.br_waves : d.tx * (d.copy16 ? 16 : d.r32 ? 8 : PXW); // bicubic_cols: four waves side by side; area_stream: 2 x 2 waves; bil_rows: br_waves side by side
+    const int tile_h = d.area_stream ? (d.as_two ? 8 * d.rpt : 16) : (d.bicubic_cols || d.bil_rows) ? 8 * d.rpt : (d.r32 || d.copy16) ? d.ty * 4 : d.ty * PXH * d.rpt;
     // dst_w = 4 k + 2: the last tile column shifted left to end at the right edge instead of a row tail and its second launch (tile_col0, vpp_device.h).
     // Not for the colour-only kernel and the box kernel (aligned dword reads at 4-column granularity), the streaming / copy kernels (never 4 k + 2), outputs
     // narrower than one tile; TSVPP_TAIL_SHIFT=0 (last_col0 < 0 on entry) keeps the tail launch of rounds 1-3.
@@ -601,6 +644,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     td.point_kind = PK_NONE; // the generic samplers give the point samplers' values (all weights are zero)
     td.area_direct = 0;
     td.bicubic_cols = 0;
+    td.bil_rows = 0;
     td.area_stream = 0;
     td.tiles_x = 1;
     td.tiles_y = (d.dst_h + td.ty * PXH - 1) / (td.ty * PXH);

@@ -1,0 +1,105 @@
+"""GPU: BILINEAR at sparse ratios on the row-segment kernel (vpp_bilinear_rows.hip: one wave per 64-column tile, the TAPPED source rows staged as
+LDS-DMA row segments, taps read from LDS) against the oracle, bit for bit -- BASELINE config C3 (crop 1280x720 -> 256x256, all horizontal weights
+zero: the `wx0` instance), the 2x2-tap instance at ratios 3.6 .. 15, every output flavour, crops with odd origins (misaligned plane pointers, the
+U / V swap quirk), widths 4 k + 2 and widths narrower than a tile, partial bottom tiles, the frame's last rows / columns (tap clamps), every
+workgroup width (1 / 2 / 4 waves), forced tile heights, forced use at small ratios (TSVPP_BILINEAR_ROWS=2 semantics through a second context is not
+needed: the ratios below select it by default), and the plan check that it IS the kernel that ran.  Pitches that are no multiple of 16 keep the
+byte-gather kernel (checked)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import synth_nv12
+
+pytestmark = pytest.mark.gpu
+
+BILINEAR = 1
+WX0, TWO = "vpp_bilinear_rows_kernel<OUT,wx0>", "vpp_bilinear_rows_kernel<OUT,2x2>"
+KNOBS = any(k.startswith("TSVPP_") for k in os.environ)  # knob runs (tools/knob_matrix.sh) pick other kernels on purpose
+
+
+def run(vpp, oracle, y, uv, w, dst, fourcc=1, planes=0, norm=True, crop=(0, 0, 0, 0), expect=None):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=BILINEAR, pixel_format=fourcc, planes_pos=planes,
+                            normalization=norm)
+    if expect is not None and not KNOBS:
+        k = ts.describe(fp, w, y.shape[0], pitch=y.shape[1])["kernel"]
+        assert k.startswith(expect), k
+    got = vpp.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=w)
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=BILINEAR, fourcc=fourcc, planes=planes, normalization=norm, nthreads=8, width=w)
+    g = got.cpu().numpy().ravel()
+    assert g.size == ref.size
+    bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+    assert bad.size == 0, (dst, fourcc, planes, norm, crop, bad[:8], bad.size)
+
+
+def test_baseline_c3(vpp, oracle):
+    y, uv = synth_nv12(1920, 1080, seed=3, pitch=2048)
+    run(vpp, oracle, y, uv, 1920, (256, 256), crop=(0, 0, 1280, 720), expect=WX0)
+    run(vpp, oracle, y, uv, 1920, (256, 256), crop=(0, 0, 1280, 720), planes=1, norm=False, expect=WX0)
+
+
+@pytest.mark.parametrize("src,dst,kernel", [
+    ((1920, 1080), (300, 300), TWO),     # 6.4 x 3.6: 27 chunks per segment, two segments per instruction, single-wave workgroups (300 = 4.7 tiles)
+    ((1920, 1080), (224, 224), TWO),     # 8.57 x 4.82: 35 chunks, one segment per instruction, two waves per workgroup
+    ((3840, 2160), (640, 360), TWO),     # 6 x 6: weights 0.5
+    ((3840, 2160), (256, 256), WX0),     # 15 x 8.4375: 61 chunks -- the widest segment one instruction takes
+    ((1920, 1080), (384, 216), WX0),     # 5 x 5: both weights zero -> the point kernel takes it; stays a plan check below
+    ((1920, 1080), (128, 60), WX0),      # 15 x 18: vertical ratio beyond any dense staging, horizontal at the limit
+    ((1280, 720), (256, 180), WX0),      # 5 x 4 (wy = 0.5)
+    ((1080, 1920), (216, 160), WX0),     # 5 x 12, portrait
+])
+def test_ratio_classes(vpp, oracle, src, dst, kernel):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0], pitch=(src[0] + 15) // 16 * 16)
+    if dst == (384, 216):
+        kernel = "vpp_point_kernel"
+    run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True, expect=kernel)
+    run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False, expect=kernel)
+
+
+@pytest.mark.parametrize("fourcc,planes,norm", [(1, 0, False), (1, 1, True), (2, 0, True), (2, 1, False), (0, 1, False), (0, 1, True), (3, 1, False),
+                                                 (3, 1, True), (6, 1, True), (4, 1, False), (5, 1, True)])
+def test_output_flavours(vpp, oracle, fourcc, planes, norm):
+    y, uv = synth_nv12(1920, 1080, seed=77 + fourcc, pitch=1920)
+    run(vpp, oracle, y, uv, 1920, (256, 256), fourcc=fourcc, planes=planes, norm=norm, crop=(0, 0, 1280, 720))  # wx0
+    run(vpp, oracle, y, uv, 1920, (300, 200), fourcc=fourcc, planes=planes, norm=norm)                           # 2x2: 6.4 x 5.4
+
+
+@pytest.mark.parametrize("pitch", [2048, 1936, 1925, 1924])
+def test_crops_tails_and_pitches(vpp, oracle, pitch):
+    """pitch % 16 == 0 keeps the kernel whatever the crop origin does to the plane pointers; other pitches fall back to byte gathers (same bits)."""
+    y, uv = synth_nv12(1920, 1080, seed=11 + pitch, pitch=pitch)
+    k = (TWO if pitch % 16 == 0 else "vpp_fused_gather_kernel")
+    run(vpp, oracle, y, uv, 1920, (310, 178), crop=(121, 65, 1721, 865), expect=k)                    # odd origin: U / V swap quirk, unaligned planes; width 4 k + 2
+    run(vpp, oracle, y, uv, 1920, (310, 178), crop=(121, 65, 1721, 865), planes=1, norm=False, expect=k)
+    run(vpp, oracle, y, uv, 1920, (250, 100), crop=(920, 580, 1920, 1080), expect=k)                  # the bottom-right corner: the planes' last rows and bytes; 4 k + 2
+    run(vpp, oracle, y, uv, 1920, (62, 30), crop=(6, 2, 1006, 482))                                   # narrower than a tile, 4 k + 2: row-tail launch
+    run(vpp, oracle, y, uv, 1920, (258, 132), planes=1, norm=False)                                   # 7.44 x 8.18, shifted last tile column (258 = 256 + 2)
+    run(vpp, oracle, y, uv, 1920, (132, 34))                                                          # 14.5 x 31.8: partial bottom tile (34 = 4 x 8 + 2)
+
+
+def test_full_frame_edges(vpp, oracle):
+    """Outputs whose last column / row tap the source's last sample (clamped right / bottom taps) and whose first taps sit at 0."""
+    for (w, h), dst in [((640, 368), (128, 64)), ((1024, 512), (64, 32)), ((2048, 64), (256, 8)), ((80, 1080), (8, 200)), ((1296, 730), (86, 72))]:
+        y, uv = synth_nv12(w, h, seed=w + h, pitch=(w + 15) // 16 * 16)
+        run(vpp, oracle, y, uv, w, dst)
+        run(vpp, oracle, y, uv, w, dst, planes=1, norm=False)
+
+
+def test_batch_and_frames_far_apart(vpp, oracle):
+    """A 64-frame batch: frame 0, a middle one and the last (the tile decode over frames)."""
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=256, height=256, crop_coords=(0, 0, 1280, 720), resize_type=BILINEAR, pixel_format=1, planes_pos=0, normalization=True)
+    n = 64
+    rng = np.random.default_rng(5)
+    ys = rng.integers(0, 256, (n, 1080, 2048), dtype=np.uint8)
+    uvs = rng.integers(0, 256, (n, 540, 2048), dtype=np.uint8)
+    out = vpp.convert_batch(torch.from_numpy(ys).cuda(), torch.from_numpy(uvs).cuda(), fp, width=1920)
+    torch.cuda.synchronize()
+    for f in (0, 29, 63):
+        ref, _, _ = oracle.convert(ys[f], uvs[f], crop=(0, 0, 1280, 720), dst=(256, 256), resize_type=BILINEAR, fourcc=1, planes=0, normalization=True,
+                                   nthreads=8, width=1920)
+        assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), f

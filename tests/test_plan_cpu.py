@@ -97,16 +97,20 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((1080, 608), (480, 360), C, "vpp_bicubic_cols_kernel<OUT,tie,dense>"),
     ((1920, 1080), (224, 224), C, "vpp_bicubic_cols_kernel<OUT,tie,sparse>"),    # vertical ratio >= 4: only the tapped rows are evaluated
     ((3840, 2160), (640, 360), C, "vpp_bicubic_cols_kernel<OUT,exact,sparse>"),  # 6: dyadic, but too sparse for the staged integer kernel
-    ((1920, 1080), (224, 224), B, "vpp_fused_gather_kernel"),            # very sparse sampling: plain gathers
+    ((1920, 1080), (224, 224), B, "vpp_bilinear_rows_kernel<OUT,2x2>"),  # very sparse sampling: the tapped rows as LDS-DMA row segments (round 5; byte gathers before)
 ])
 def test_kernel_families(src, dst, rt, kernel):
     p = plan(src, dst, rt)
     assert p["kernel"].startswith(kernel), p
 
 
-def test_c3_crop_folds_into_pointers_and_the_sparse_bilinear_gathers():
+def test_c3_crop_folds_into_pointers_and_the_sparse_bilinear_streams_its_rows():
     p = plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=2048)
-    assert (p["src"], p["dst"]) == ("1280x720", "256x256") and p["kernel"].startswith("vpp_fused_gather_kernel")
+    assert (p["src"], p["dst"]) == ("1280x720", "256x256") and p["kernel"] == "vpp_bilinear_rows_kernel<OUT,wx0>", p  # 5.0 x 2.8125: every horizontal weight is zero
+    assert (p["tiles"], p["shape"], p["lds"]) == ("1x32", "16x4", 4 * (3 * 8 * 16 * 21 + 64)), p                       # four waves side by side, 21 chunks per row segment
+    # a pitch that is no multiple of 16 (rows with different misalignments), unaligned outputs: byte gathers
+    assert plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=1924)["kernel"].startswith("vpp_fused_gather_kernel")
+    assert plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=2048, aligned_outputs=False)["kernel"] == "vpp_fused_gather_kernel<MODE,OUT,false>"
 
 
 def test_small_outputs_keep_two_row_thread_tiles():
