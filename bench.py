@@ -42,6 +42,7 @@ for _p in (ROOT, os.path.join(ROOT, "tensor-stream_amd")):
 import numpy as np
 
 MAX_LAUNCH = 128      # frames per launch (include/tsvpp.h: TSVPP_MAX_BATCH)
+MAX_TABLE_LAUNCH = 1024  # ... out of a persistent device-resident frame table (TSVPP_MAX_TABLE_LAUNCH; --table)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 METRIC = "1080p NV12→720p BGR24 planar fp32 frames/sec per GPU; achieved HBM GB/s vs roofline"
 
@@ -335,6 +336,8 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is run this many times and the median is reported; "
                     "0 = max(5, ceil(400 / steps)): SURVEY.md 8(d) asks for >= 200 timed iterations and a median of 5; 400 keep the clock ramp of the first ~25 ms out of the median")
     ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per MAX_LAUNCH = 128 frames: tsvpp.h TSVPP_MAX_BATCH)")
+    ap.add_argument("--table", action="store_true", help="register every buffer set ONCE in a persistent device-resident frame table (tsvpp_table_*) and convert it with "
+                    "tsvpp_convert_table: launches of up to 1024 frames (--batch may then exceed 128 per launch); the pools of a real pipeline come round again the same way")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--alias", type=int, default=0, help="DIAGNOSTIC (not a measurement of the path): bit 0 = all frames of a launch read one "
                     "input frame, bit 1 = all write one output buffer, so that reads / writes stay in cache; separates issue-bound from memory-bound kernels")
@@ -463,7 +466,7 @@ class GpuWork:
     """One workload resident in HBM: `sets` rotating buffer sets of B synthetic frames (distinct per frame / set / rank)
     and the prebuilt batch descriptors (a step is then one C-ABI call per `per_call` frames)."""
 
-    def __init__(self, eng, spec, B, sets, seed, alias=0, per_call=0):
+    def __init__(self, eng, spec, B, sets, seed, alias=0, per_call=0, table=False):
         torch, ts, vpp = eng.torch, eng.ts, eng.vpp
         src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
         self.spec, self.B, self.torch = spec, B, torch
@@ -487,6 +490,15 @@ class GpuWork:
         self.batches = [[vpp.make_batch(ys[k:k + F], uvs[k:k + F], self.fp, out=out[k:k + F], width=src_w) for k in range(0, B, F)]
                         for (ys, uvs, out) in self.sets]
         self.launches_per_step = ((F + MAX_LAUNCH - 1) // MAX_LAUNCH) * (B // F) + ((B % F + MAX_LAUNCH - 1) // MAX_LAUNCH)
+        self.tables = None
+        if table:  # the same buffer sets, registered once: a step is ONE tsvpp_convert_table call over the whole set
+            self.tables = [vpp.make_table(ys, uvs, self.fp, out=out, width=src_w) for (ys, uvs, out) in self.sets]
+            _, _, dw, dh = roi_and_dst(src_w, src_h, crop, dst)
+            cap = max(MAX_LAUNCH, min(MAX_TABLE_LAUNCH, ((1 << 31) // 256) // max(1, ((dw + 63) // 64) * ((dh + 3) // 4))))  # tsvpp_api.cpp: convert_impl
+            two_pass = fcc in ("UYVY", "YUV444") and "pass2" in str(ts.describe(self.fp, src_w, src_h, pitch=pitch, n_frames=min(B, MAX_LAUNCH)))
+            if two_pass:
+                cap = MAX_LAUNCH
+            self.launches_per_step = (B + cap - 1) // cap
         self.frames_per_launch = B / self.launches_per_step
         self.vpp = vpp
 
@@ -509,6 +521,9 @@ class GpuWork:
         return True, frames
 
     def issue(self, i, stream):
+        if self.tables is not None:
+            self.vpp.run_table(self.tables[i % len(self.tables)], stream=stream)
+            return
         for b in self.batches[i % len(self.batches)]:
             self.vpp.run_batch(b, stream)
 
@@ -526,7 +541,7 @@ class GpuEngine:
         self.coeffs = parallel.broadcast_coeffs(self.vpp, dist)
         self.coeff_broadcast = parallel.last_broadcast_info()
         B = args.batch
-        self.work = GpuWork(self, spec, B, args.sets, 1234 + rank, alias=args.alias, per_call=args.per_call)
+        self.work = GpuWork(self, spec, B, args.sets, 1234 + rank, alias=args.alias, per_call=args.per_call, table=getattr(args, "table", False))
         self.fp = self.work.fp
         self.ws_mib = self.work.ws_mib
         self.launches_per_step = self.work.launches_per_step
@@ -851,7 +866,7 @@ def run(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if norm else "u8", "data": "stub" if stub else "synthetic",
             "config": {"workload": f"{src_w}x{src_h} NV12 (pitch {pitch}) crop{list(crop)} -> {dst[0] or src_w}x{dst[1] or src_h} "
                                    f"{rt if dst[0] else 'no-resize'} -> {fcc} {planes} {'fp32 /255' if norm else 'uint8'}",
-                       "name": name, "frames_per_step": B, "frames_per_launch": fpl, "hip_graph": bool(eng.graphs),
+                       "name": name, "frames_per_step": B, "frames_per_launch": fpl, "hip_graph": bool(eng.graphs), "frame_table": bool(getattr(args, "table", False)),
                        "buffer_sets": args.sets, "working_set_MiB": round(eng.ws_mib, 1), "sharding": f"frames/{world} ranks, no data collective",
                        "parity": eng.parity},
             "timing": {"repeats": len(reps), "reported": "median repeat (max over ranks per repeat)",

@@ -121,6 +121,25 @@ int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, v
  * (Not in the reference: one 1080p frame is ~2.5 us of HBM time, below a launch.) */
 int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream);
 
+/* ---- persistent frame tables (round 5; not in the reference) ------------------------------------------------------------------------------------------
+ * tsvpp_convert_batch passes its (y, uv, out) pointer triples by value in the kernarg segment: no copy, no device-side descriptor -- and at most
+ * TSVPP_MAX_BATCH frames per launch.  A pipeline whose decoder surfaces and output buffers are POOLS (the usual case: the same surfaces and tensors come
+ * round again) can instead register them once in a device-resident table and convert any run of its entries with launches of up to
+ * TSVPP_MAX_TABLE_LAUNCH frames: the small-output configurations (BASELINE C3: 1.8 MB per frame) move 0.64 of the HBM roofline in 64-frame launches and
+ * 0.70+ from 256 frames on (profiles/r05_table_ab.txt); nothing is copied per call.
+ *   tsvpp_table_create    `capacity` entries; every entry shares one geometry (width, height, pitches: fixed by the first tsvpp_table_set).
+ *   tsvpp_table_set       entries [first, first + n) <- in[i] / outs[i] (HOST arrays); uploaded on `stream` out of a pinned mirror the table owns: the arrays may be
+ *                         freed on return, conversions enqueued on the same stream afterwards see the new entries.
+ *   tsvpp_convert_table   == tsvpp_convert_batch over entries [first, first + n), same results, same status codes.
+ *   tsvpp_table_destroy   frees the table (the caller has waited for conversions that use it).
+ * A table belongs to the context that created it (its device). */
+#define TSVPP_MAX_TABLE_LAUNCH 1024
+typedef struct tsvpp_table tsvpp_table;
+int tsvpp_table_create(tsvpp_ctx *ctx, int capacity, tsvpp_table **out_table);
+void tsvpp_table_destroy(tsvpp_table *table);
+int tsvpp_table_set(tsvpp_table *table, int first, int n, const tsvpp_nv12 *in, void *const *outs, void *stream);
+int tsvpp_convert_table(tsvpp_ctx *ctx, const tsvpp_table *table, int first, int n, const tsvpp_params *p, void *stream);
+
 /* Pre-build everything a (params, input size) pair needs so that later tsvpp_convert* calls for it touch no
  * allocator -- e.g. before hipGraph capture: the AREA weight tables (the reference mallocs, copies and leaks them
  * per frame, src/Resize.cu:389-406,436-452) and, for UYVY / YUV444 behind a resize, the resized-NV12 scratch of

@@ -249,6 +249,7 @@ struct tsvpp_ctx {
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int bilinear_rows = 1;          // TSVPP_BILINEAR_ROWS: BILINEAR at sparse ratios with the tapped rows as LDS-DMA row segments (vpp_bilinear_rows.hip; 1: ratio product >= 12, 2: wherever it applies, 0: byte gathers)
+    int point_rn = 1;               // TSVPP_POINT_RN: streaming point sampler at exact integer ratios 3 / 4 / 5 (vpp_point_rn.hip; 0: the LDS point kernel)
     int bilinear_rows_waves = 0;    // TSVPP_BILINEAR_ROWS_WAVES: its waves per workgroup (1 / 2 / 4; 0 = automatic)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
     GeoCache *geo = nullptr;        // ... their device copies, one set per (request geometry, tile shape)
@@ -356,6 +357,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS")) ctx->bilinear_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_POINT_RN")) ctx->point_rn = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS_WAVES")) ctx->bilinear_rows_waves = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_STREAM")) ctx->area_stream = std::atoi(e);
@@ -416,6 +418,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.geo_pref = ctx->geo_pref;
     d.r32_pref = ctx->r32;
     d.bil_rows_pref = ctx->bilinear_rows;
+    d.point_rn_pref = ctx->point_rn;
     d.br_waves = ctx->bilinear_rows_waves; // (forced; launch_fused chooses)
     d.geo_cache = ctx->geo;
 }
@@ -798,7 +801,13 @@ static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void 
     return launch_fused(pl.mode, pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8, true, dd, t, stream, &info) == hipSuccess;
 }
 
-int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
+// Device-resident columns of a tsvpp_table, already advanced to the run's first entry (null: the pointer triples travel in the kernarg segment).
+struct TableCols {
+    const uint64_t *y = nullptr, *uv = nullptr, *out = nullptr;
+};
+
+// tsvpp_convert_batch and tsvpp_convert_table: `in` / `outs` are HOST arrays of the n frames (a table's pinned mirror for the latter).
+static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream, const TableCols &tab) {
     if (!ctx || !in || !p || !outs || n < 0) return TSVPP_ERROR;
     if (n == 0) return TSVPP_OK;
     Plan pl;
@@ -889,18 +898,32 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     }
     const OutKind out_kind = single ? (pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8) : pl.out;
     if (two_pass && d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
-    for (int base = 0; base < n; base += TSVPP_MAX_BATCH) {
-        const int cnt = (n - base < TSVPP_MAX_BATCH) ? n - base : TSVPP_MAX_BATCH;
-        FrameTable t;
-        for (int f = 0; f < TSVPP_MAX_BATCH; f++) {
-            t.y[f] = nullptr;
-            t.uv[f] = nullptr;
-            t.out[f] = nullptr;
-        }
-        for (int f = 0; f < cnt; f++) {
-            t.y[f] = in[base + f].y + y_off;
-            t.uv[f] = in[base + f].uv + uv_off;
-            t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
+    // Frames per launch: TSVPP_MAX_BATCH with the pointer triples in the kernarg segment; out of a device-resident table (single-pass requests) up to
+    // TSVPP_MAX_TABLE_LAUNCH, less where the grid would outgrow 2^31 threads (the smallest tile any kernel uses is 64 x 4 output pixels per workgroup of 256).
+    const bool from_table = tab.y != nullptr && !two_pass;
+    int max_launch = TSVPP_MAX_BATCH;
+    if (from_table) {
+        const long wg_per_frame = (long)((pl.dst_w + 63) / 64) * ((pl.dst_h + 3) / 4);
+        long cap = ((1L << 31) / 256) / (wg_per_frame > 0 ? wg_per_frame : 1);
+        if (cap > TSVPP_MAX_TABLE_LAUNCH) cap = TSVPP_MAX_TABLE_LAUNCH;
+        if (cap > TSVPP_MAX_BATCH) max_launch = (int)cap;
+    }
+    for (int base = 0; base < n; base += max_launch) {
+        const int cnt = (n - base < max_launch) ? n - base : max_launch;
+        FrameTable t = {};
+        if (from_table) {
+            t.y.ext = (const uint8_t *const *)(tab.y + base);
+            t.y.off = (int64_t)y_off;
+            t.uv.ext = (const uint8_t *const *)(tab.uv + base);
+            t.uv.off = (int64_t)uv_off;
+            t.out.ext = (void *const *)(tab.out + base);
+            t.out.off = 0;
+        } else {
+            for (int f = 0; f < cnt; f++) {
+                t.y[f] = in[base + f].y + y_off;
+                t.uv[f] = in[base + f].uv + uv_off;
+                t.out[f] = (two_pass && pl.mode != M_NONE) ? (void *)(scratch + (size_t)(base + f) * frame_scratch) : outs[base + f];
+            }
         }
         d.n_frames = cnt;
         // Vector-store kernels need 16-byte aligned outputs (else: the element-wise gather kernel); scratch frames are
@@ -928,6 +951,107 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         }
     }
     return TSVPP_OK;
+}
+
+int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
+    return convert_impl(ctx, n, in, p, outs, stream, TableCols());
+}
+
+// ---- persistent frame tables (include/tsvpp.h) --------------------------------------------------------------------------------------------------------
+struct tsvpp_table {
+    tsvpp_ctx *ctx = nullptr;
+    int capacity = 0;
+    uint64_t *dev = nullptr;    // three columns of `capacity` entries: y | uv | out
+    uint64_t *pinned = nullptr; // the same layout in pinned host memory: the source of every upload
+    std::vector<tsvpp_nv12> in; // host mirror (geometry checks, alignment decisions, the two-pass formats)
+    std::vector<void *> outs;
+    std::vector<uint8_t> set;   // entry has been set
+    bool have_geom = false;
+    tsvpp_nv12 geom = {};
+    std::mutex mu;
+};
+
+int tsvpp_table_create(tsvpp_ctx *ctx, int capacity, tsvpp_table **out_table) {
+    if (!ctx || !out_table || capacity < 1 || capacity > (1 << 24)) return TSVPP_ERROR;
+    *out_table = nullptr;
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
+    tsvpp_table *t = new tsvpp_table;
+    t->ctx = ctx;
+    t->capacity = capacity;
+    const size_t bytes = (size_t)3 * capacity * sizeof(uint64_t);
+    hipError_t e = hipMalloc((void **)&t->dev, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&t->pinned, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(t->dev, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (t->dev) (void)hipFree(t->dev);
+        if (t->pinned) (void)hipHostFree(t->pinned);
+        delete t;
+        return (int)e;
+    }
+    std::memset(t->pinned, 0, bytes);
+    t->in.resize((size_t)capacity);
+    t->outs.assign((size_t)capacity, nullptr);
+    t->set.assign((size_t)capacity, 0);
+    *out_table = t;
+    return TSVPP_OK;
+}
+
+void tsvpp_table_destroy(tsvpp_table *table) {
+    if (!table) return;
+    {
+        DeviceGuard guard(table->ctx);
+        if (table->dev) (void)hipFree(table->dev);
+        if (table->pinned) (void)hipHostFree(table->pinned);
+    }
+    delete table;
+}
+
+int tsvpp_table_set(tsvpp_table *table, int first, int n, const tsvpp_nv12 *in, void *const *outs, void *stream) {
+    if (!table || !in || !outs || first < 0 || n < 0 || (long)first + n > table->capacity) return TSVPP_ERROR;
+    if (n == 0) return TSVPP_OK;
+    std::lock_guard<std::mutex> lk(table->mu);
+    const tsvpp_nv12 g = table->have_geom ? table->geom : in[0];
+    const int gpy = g.pitch_y ? g.pitch_y : g.width, gpuv = g.pitch_uv ? g.pitch_uv : g.width;
+    for (int f = 0; f < n; f++) { // one geometry per table, as one per batch (tsvpp_convert_batch)
+        if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
+        if (in[f].width != g.width || in[f].height != g.height) return TSVPP_UNSUPPORTED;
+        if ((in[f].pitch_y ? in[f].pitch_y : in[f].width) != gpy || (in[f].pitch_uv ? in[f].pitch_uv : in[f].width) != gpuv) return TSVPP_UNSUPPORTED;
+    }
+    DeviceGuard guard(table->ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
+    const size_t cap = (size_t)table->capacity;
+    for (int f = 0; f < n; f++) {
+        const size_t k = (size_t)first + f;
+        table->in[k] = in[f];
+        table->outs[k] = outs[f];
+        table->set[k] = 1;
+        table->pinned[k] = (uint64_t)(uintptr_t)in[f].y;
+        table->pinned[cap + k] = (uint64_t)(uintptr_t)in[f].uv;
+        table->pinned[2 * cap + k] = (uint64_t)(uintptr_t)outs[f];
+    }
+    table->geom = g;
+    table->have_geom = true;
+    for (int col = 0; col < 3; col++) { // the three column ranges, out of the pinned mirror: asynchronous, ordered on `stream`
+        hipError_t e = hipMemcpyAsync(table->dev + col * cap + first, table->pinned + col * cap + first, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return TSVPP_OK;
+}
+
+int tsvpp_convert_table(tsvpp_ctx *ctx, const tsvpp_table *table, int first, int n, const tsvpp_params *p, void *stream) {
+    if (!ctx || !table || table->ctx != ctx || !p || first < 0 || n < 0 || (long)first + n > table->capacity) return TSVPP_ERROR;
+    if (n == 0) return TSVPP_OK;
+    for (int f = 0; f < n; f++)
+        if (!table->set[(size_t)first + f]) return TSVPP_ERROR; // an entry that was never set
+    const size_t cap = (size_t)table->capacity;
+    TableCols cols;
+    cols.y = table->dev + first;
+    cols.uv = table->dev + cap + first;
+    cols.out = table->dev + 2 * cap + first;
+    return convert_impl(ctx, n, table->in.data() + first, p, table->outs.data() + first, stream, cols);
 }
 
 int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, void *out, void *stream) {

@@ -196,9 +196,10 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_int_kernel(const Laun
         }
     }
     __syncthreads();
-#ifdef TSVPP_DEBUG_LDS // debugging aid (make DEBUG_LDS=1): workgroup 0 copies its whole LDS image to the buffer smuggled in t.out[63]
-    if (blockIdx.x == 0 && t.out[TSVPP_MAX_BATCH - 1] != nullptr) {
-        uint32_t *dst = (uint32_t *)t.out[TSVPP_MAX_BATCH - 1];
+#ifdef TSVPP_DEBUG_LDS // debugging aid (make DEBUG_LDS=1): workgroup 0 copies its whole LDS image to the buffer smuggled in the kernarg table's LAST slot --
+    // only in launches that do not use that slot for a frame (a full 128-frame batch has a real output pointer there)
+    if (blockIdx.x == 0 && !t.out.ext && d.n_frames < TSVPP_MAX_BATCH && t.out.v[TSVPP_MAX_BATCH - 1] != nullptr) {
+        uint32_t *dst = (uint32_t *)t.out.v[TSVPP_MAX_BATCH - 1];
         const int nd = (int)(((uint8_t *)(rbuv + nrb_uv) - lds_raw + 3) / 4);
         for (int i = threadIdx.x; i < nd; i += nthreads) dst[i] = ((const uint32_t *)lds_raw)[i];
     }

@@ -3,7 +3,7 @@
 //   UYVY      4:2:0 -> 4:2:2, vertical (-1, 9, 9, -1)/16 chroma filter on odd chroma rows  reference src/ColorConversion.cu:107-127, 177-209
 //   YUV444    UYVY -> planar 4:4:4, horizontal (-1, 9, 9, -1)/16 filter on odd pixels      :129-173
 // (Y800, NV12 and HSV are output flavours of the fused kernels, vpp_kernels.hip.)  One launch per batch
-// of <= 64 frames (pointer table in the kernarg segment), thread = two horizontal pixel pairs.  Same arithmetic contract as vpp_kernels.hip: plain IEEE,
+// of <= TSVPP_MAX_BATCH (128) frames (pointer table in the kernarg segment), thread = two horizontal pixel pairs.  Same arithmetic contract as vpp_kernels.hip: plain IEEE,
 // no contraction; integer paths use C integer semantics exactly as the reference's <uchar> code.
 #include "vpp_kernels.h"
 

@@ -20,13 +20,33 @@ namespace tsvpp {
 // dispatch does (src/Resize.cu:435): weighted box if both ratios > 1, else the bilinear variant.
 enum Mode : int { M_NONE = 0, M_NEAREST, M_BILINEAR, M_BICUBIC, M_AREA_DOWN, M_AREA_UP, M_COUNT };
 
-// Per-launch pointer table, passed BY VALUE in the kernarg segment (1.5 KiB): the kernel
-// reads its frame's three pointers with scalar loads, no device-side descriptor buffer and
-// no host->device copy per batch.
+// Per-launch pointer table.  Launches of up to TSVPP_MAX_BATCH frames carry it BY VALUE in the kernarg segment (3 KiB): the kernel reads its frame's three
+// pointers with scalar loads, no device-side descriptor buffer and no host->device copy per batch.  Launches out of a persistent, device-resident table
+// (tsvpp_table, round 5: up to TSVPP_MAX_TABLE_LAUNCH frames per launch) set `ext` instead: the same scalar loads, through the constant address space, off
+// the table's column + `off` (the crop origin, which belongs to the request, not to the table).  Kernels index both the same way: t.y[frame].
+template <class T> struct PtrCol {
+    T v[TSVPP_MAX_BATCH];
+    const T *ext; // device memory, or null
+    int64_t off;  // bytes added to every `ext` entry
+    __host__ __device__ __forceinline__ T operator[](int f) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ext) {
+            typedef const __attribute__((address_space(4))) uint64_t *CP; // written by the host before the launch, never by a kernel: scalar loads
+            typedef __attribute__((address_space(1))) uint8_t *GP;        // ... and what they hold are GLOBAL addresses: without this the kernels' loads / stores become flat_*
+            return (T)(GP)(uintptr_t)(((CP)(uintptr_t)ext)[f] + (uint64_t)off);
+        }
+        {
+            typedef __attribute__((address_space(1))) uint8_t *GP;
+            return (T)(GP)(uintptr_t)v[f];
+        }
+#endif
+        return v[f]; // (host: only tables without `ext` are read back, vpp_formats.hip)
+    }
+    __host__ __forceinline__ T &operator[](int f) { return v[f]; }
+};
 struct FrameTable {
-    const uint8_t *y[TSVPP_MAX_BATCH];
-    const uint8_t *uv[TSVPP_MAX_BATCH];
-    void *out[TSVPP_MAX_BATCH];
+    PtrCol<const uint8_t *> y, uv;
+    PtrCol<void *> out;
 };
 
 // One row of an AREA weight table quantised to integers (weights * 2^shift), for requests whose
@@ -142,8 +162,12 @@ struct LaunchDesc {
     // byte-gather kernel ran until round 4 -- ratio product >= 12 --, 2 = wherever a segment fits one DMA instruction, 0 = never) / chosen by launch_fused: the 16-byte chunks of one
     // row segment (<= 64), 0 = off; br_waves: waves (64-column tiles) per workgroup; br_rpi: segments per DMA instruction (64 / bil_rows).  A wave's LDS bytes travel in bc_wave_bytes.
     int bil_rows_pref, bil_rows, br_waves, br_rpi;
+    int point_rn_pref; // TSVPP_POINT_RN: streaming point sampler at exact integer ratios (vpp_point_rn.hip) allowed; chosen: r32 >= 100
     GeoCache *geo_cache;
 };
+
+//  everything a kernel receives travels in the kernarg segment: 4 KiB, of which HIP's hidden arguments take up to 256 bytes
+static_assert(sizeof(LaunchDesc) + sizeof(FrameTable) + 256 <= 4096, "LaunchDesc + FrameTable no longer fit the kernarg segment");
 
 // Device-resident geometry tables, one set per (kind, request geometry, tile shape); owned by a context, freed with it.
 struct GeoKey {
@@ -234,6 +258,9 @@ hipError_t launch_area_box(OutKind out, const LaunchDesc &d, const FrameTable &t
 
 // BICUBIC at exactly 3 : 2 / 2 : 1 on both axes, every output flavour, straight from global memory (vpp_bicubic_r32.hip; d.r32 = 7 / 8).
 hipError_t launch_bicubic_r32(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
+
+// Pure point samplers (NEAREST; BILINEAR / BICUBIC with all-zero weights) at an exact integer ratio 3 / 4 / 5 on both axes, streaming (vpp_point_rn.hip; d.r32 = 100 + 10 N + OFF).
+hipError_t launch_point_rn(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info);
 
 // BILINEAR at sparse ratios: the tapped rows as LDS-DMA row segments, one wave per tile (vpp_bilinear_rows.hip; d.bil_rows).
 hipError_t launch_bilinear_rows(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info);

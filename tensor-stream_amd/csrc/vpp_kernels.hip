@@ -942,6 +942,9 @@ static hipError_t launch_point(const LaunchDesc &d, const FrameTable &t, size_t 
 template <int MODE, int OUT>
 static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
+    if constexpr (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC) {
+        if (d.r32 >= 100) return launch_point_rn((OutKind)OUT, d, t, stream, info);
+    }
     if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
         return launch_point<OUT>(d, t, lds_bytes, stream, info);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_DOWN || MODE == M_NEAREST) {

@@ -47,8 +47,21 @@ static const StreamRow kStreamRows[] = {
 };
 // The streaming kernel instance of this request, or 0.  `mode` is the mode the launch runs as (an AREA request that took the 2x2-tap integer tile,
 // LaunchDesc::tap22, arrives here as BILINEAR and is not eligible: fp32 RGB).
-static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d) {
+// `point_kind`: the request's PointKind as the host decided it (launch_fused's copy may have been cleared by sel_point).
+static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d, int point_kind) {
     if (!vec || d.force_gather || !d.in_aligned4 || (d.dst_w & 7) != 0 || (d.dst_h & 3) != 0) return 0;
+    // pure point samplers at an exact integer ratio 3 / 4 / 5 on both axes (vpp_point_rn.hip): r32 = 100 + 10 N + OFF, OFF = the tap's offset inside its N samples --
+    // 0 for NEAREST, (N - 1) / 2 for the BILINEAR / BICUBIC requests whose weights are all zero (N odd).  Every flavour of the colour back end.
+    // profiles/r05_point_rn_ab.txt: C4 (4K -> 720p BICUBIC -> BGR24 merged uint8) against vpp_point_kernel
+    // uint8 flavours only (TSVPP_POINT_RN=2: fp32 too): fp32 outputs lose 5..12 % against the LDS point kernel, whose 4 x 2 thread tiles store whole lines without an exchange
+    const bool prn_u8 = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8);
+    if (point_kind != PK_NONE && d.point_rn_pref && out < O_COUNT && (prn_u8 || d.point_rn_pref == 2) && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC)) {
+        for (int n = 3; n <= 5; n++)
+            if ((long)d.src_w == (long)n * d.dst_w && (long)d.src_h == (long)n * d.dst_h) {
+                if (point_kind == PK_NEAREST) return 100 + 10 * n;
+                if (n & 1) return 100 + 10 * n + (n - 1) / 2;
+            }
+    }
     const int p2 = (2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h) ? 3 : ((d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h) ? 4 :
                    ((2 * d.src_w == d.dst_w && 2 * d.src_h == d.dst_h) ? 1 : 0));
     if (!p2) return 0;
@@ -82,6 +95,10 @@ static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int
     auto waste = [&](int w) { return (double)((n + w - 1) / w * w) / (double)n - 1.0; };
     tx = 64;
     ty = 4;
+    if (r32 >= 100) { // streaming point samplers: as the 2x2-tap kinds below
+        if (f32_out) ty = out == O_HSV_F32 ? 4 : 2;
+        return;
+    }
     if (r32 == 10) return; // the 1 : 2 up-scale: 64 x 4 threads (neighbour dwords by wave shuffle; not swept yet)
     if (r32 < 7) {
         if (f32_out) ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
@@ -557,7 +574,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
     // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
-    const int stream_r32 = stream_select(mode, out, vec, d);
+    const int stream_r32 = stream_select(mode, out, vec, d, din.point_kind);
     const int bc_r32 = (stream_r32 == 7 || stream_r32 == 8) ? stream_r32 : 0;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;

@@ -35,7 +35,8 @@ class Coeffs(ctypes.Structure):
 # every symbol include/tsvpp.h declares (tests check that the library exports all of them)
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
            "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs",
-           "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version"]
+           "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version",
+           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table"]
 
 _lib = None
 
@@ -62,6 +63,11 @@ def lib():
     L.tsvpp_channels.restype = ctypes.c_float
     L.tsvpp_convert.argtypes = [vp, pn, pp, vp, vp]
     L.tsvpp_convert_batch.argtypes = [vp, i32, pn, pp, ctypes.POINTER(vp), vp]
+    L.tsvpp_table_create.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    L.tsvpp_table_destroy.argtypes = [vp]
+    L.tsvpp_table_destroy.restype = None
+    L.tsvpp_table_set.argtypes = [vp, i32, i32, pn, ctypes.POINTER(vp), vp]
+    L.tsvpp_convert_table.argtypes = [vp, vp, i32, i32, pp, vp]
     L.tsvpp_prepare.argtypes = [vp, pp, i32, i32]
     L.tsvpp_prepare_batch.argtypes = [vp, pp, i32, i32, i32, vp]
     L.tsvpp_enable_markers.argtypes = [vp, i32]
@@ -76,7 +82,8 @@ def lib():
     L.tsvpp_version.argtypes = []
     L.tsvpp_version.restype = ctypes.c_char_p
     for f in ("tsvpp_create", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_convert", "tsvpp_convert_batch",
-              "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern", "tsvpp_describe"):
+              "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs", "tsvpp_set_coeffs", "tsvpp_area_pattern", "tsvpp_describe",
+              "tsvpp_table_create", "tsvpp_table_set", "tsvpp_convert_table"):
         getattr(L, f).restype = i32
     _lib = L
     return L

@@ -79,6 +79,7 @@ class VideoProcessor:
 
     def __init__(self, device=None, max_consumers=5):
         self._ctx = ctypes.c_void_p()
+        self._tables = []    # persistent frame tables (make_table): destroyed before the context
         self._lib = N.lib()  # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("VideoProcessor needs a ROCm GPU (gfx950); there is no CPU fallback")
@@ -88,6 +89,11 @@ class VideoProcessor:
     # reference naming
     def Close(self):
         if self._ctx:
+            if self._tables:
+                torch.cuda.synchronize(self.device)
+                for h in self._tables:
+                    self._lib.tsvpp_table_destroy(h)
+                self._tables = []
             self._lib.tsvpp_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 
@@ -203,6 +209,40 @@ class VideoProcessor:
         N.check(self._lib.tsvpp_convert_batch(self._ctx, batch["n"], batch["frames"], ctypes.byref(batch["params"]),
                                               batch["outs"], stream))
         return batch["out"]
+
+    def make_table(self, ys, uvs, params, out=None, width=None, height=None):
+        """A persistent, device-resident frame table (tsvpp_table_*, include/tsvpp.h) over a POOL of input frames and output tensors: registered once, any
+        run of its entries is then converted by run_table() with launches of up to 1024 frames and no per-call pointer traffic.  ys / uvs / out as for
+        convert_batch; the handle keeps the tensors alive; free_table() (or Close) releases the table."""
+        p = params.parameters if isinstance(params, FrameParameters) else params
+        n = len(ys)
+        frames = (N.NV12 * n)(*[self._frame(ys[i], uvs[i], width, height) for i in range(n)])
+        if out is None:
+            out = self._alloc(p, frames[0].width, frames[0].height, n)
+        outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        h = ctypes.c_void_p()
+        N.check(self._lib.tsvpp_table_create(self._ctx, n, ctypes.byref(h)))
+        self._tables.append(h)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.tsvpp_table_set(h, 0, n, frames, outs, stream))
+        return {"n": n, "handle": h, "params": p, "out": out, "keep": (ys, uvs)}
+
+    def run_table(self, table, first=0, n=None, params=None, stream=None):
+        """Converts entries [first, first + n) of a table made by make_table (default: all of it, with the parameters it was made with)."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        p = table["params"] if params is None else (params.parameters if isinstance(params, FrameParameters) else params)
+        cnt = table["n"] - first if n is None else n
+        N.check(self._lib.tsvpp_convert_table(self._ctx, table["handle"], first, cnt, ctypes.byref(p), stream))
+        return table["out"]
+
+    def free_table(self, table):
+        h = table.get("handle")
+        if h is not None and any(h is t for t in self._tables):
+            torch.cuda.synchronize(self.device)
+            self._lib.tsvpp_table_destroy(h)
+            self._tables = [t for t in self._tables if t is not h]
+            table["handle"] = None
 
     def _on_consumer_stream(self, name):
         raw = self.consumer_stream(name)

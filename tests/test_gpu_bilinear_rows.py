@@ -47,17 +47,16 @@ def test_baseline_c3(vpp, oracle):
     ((1920, 1080), (224, 224), TWO),     # 8.57 x 4.82: 35 chunks, one segment per instruction, two waves per workgroup
     ((3840, 2160), (640, 360), TWO),     # 6 x 6: weights 0.5
     ((3840, 2160), (256, 256), WX0),     # 15 x 8.4375: 61 chunks -- the widest segment one instruction takes
-    ((1920, 1080), (384, 216), WX0),     # 5 x 5: both weights zero -> the point kernel takes it; stays a plan check below
+    ((1920, 1080), (384, 216), WX0),     # 5 x 5: both weights zero -> a point sampler takes it; stays a plan check below
     ((1920, 1080), (128, 60), WX0),      # 15 x 18: vertical ratio beyond any dense staging, horizontal at the limit
     ((1280, 720), (256, 180), WX0),      # 5 x 4 (wy = 0.5)
     ((1080, 1920), (216, 160), WX0),     # 5 x 12, portrait
 ])
 def test_ratio_classes(vpp, oracle, src, dst, kernel):
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0], pitch=(src[0] + 15) // 16 * 16)
-    if dst == (384, 216):
-        kernel = "vpp_point_kernel"
-    run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True, expect=kernel)
-    run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False, expect=kernel)
+    point = dst == (384, 216)  # 5 x 5: both axes' weights are zero -> a point sampler (fp32: the LDS one, uint8: the streaming one at an exact integer ratio)
+    run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True, expect="vpp_point_kernel" if point else kernel)
+    run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False, expect="vpp_point_rn_kernel" if point else kernel)
 
 
 @pytest.mark.parametrize("fourcc,planes,norm", [(1, 0, False), (1, 1, True), (2, 0, True), (2, 1, False), (0, 1, False), (0, 1, True), (3, 1, False),

@@ -1,0 +1,150 @@
+"""GPU: persistent device-resident frame tables (tsvpp_table_create / _set / tsvpp_convert_table, include/tsvpp.h) -- launches of more than
+TSVPP_MAX_BATCH frames whose pointer triples are read from device memory instead of the kernarg segment.  Every kernel family must produce the same
+bits through the table as through tsvpp_convert_batch (and the oracle): the indirection lives in ONE accessor (vpp_kernels.h: PtrCol), the tests
+sweep the kernels that use it.  Also: runs that start inside the table, entries replaced after creation, crops (the origin travels with the request,
+not with the table), the two-pass formats (which fall back to kernarg launches over the table's host mirror) and the error paths."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 300  # > 2 x TSVPP_MAX_BATCH: one table launch where convert_batch needs three
+
+
+def _pool(w, h, pitch, n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ys = torch.randint(0, 256, (n, h, pitch), dtype=torch.uint8, device="cuda", generator=g)
+    uvs = torch.randint(0, 256, (n, h // 2, pitch), dtype=torch.uint8, device="cuda", generator=g)
+    return ys, uvs
+
+
+def _check(oracle, ys, uvs, out, f, w, crop, dst, rt, fourcc, planes, norm):
+    ref, _, _ = oracle.convert(ys[f].cpu().numpy(), uvs[f].cpu().numpy(), crop=crop, dst=dst, resize_type=rt, fourcc=fourcc, planes=planes,
+                               normalization=norm, nthreads=8, width=w)
+    got = out[f].cpu().numpy().ravel()
+    assert got.size == ref.size and np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (f, dst, rt, fourcc, planes, norm)
+
+
+CASES = [
+    # src, dst, resize, fourcc, planes, norm, crop                       (the kernel family each one lands on)
+    ((640, 360), (0, 0), 0, 2, 0, True, (0, 0, 0, 0)),          # colour only
+    ((640, 360), (0, 0), 0, 0, 1, False, (0, 0, 0, 0)),         # Y800 copy
+    ((1280, 720), (256, 256), 1, 1, 0, True, (0, 0, 0, 0)),     # BILINEAR 5 x 2.8125: row segments (C3's geometry)
+    ((960, 540), (640, 360), 1, 2, 0, True, (0, 0, 0, 0)),      # BILINEAR 3 : 2, LDS window tile
+    ((960, 540), (640, 360), 1, 1, 1, False, (0, 0, 0, 0)),     # ... uint8: streaming kernel
+    ((960, 540), (640, 360), 2, 2, 1, False, (0, 0, 0, 0)),     # BICUBIC 3 : 2 streaming
+    ((960, 544), (320, 136), 2, 2, 1, False, (0, 0, 0, 0)),     # BICUBIC 3 x 4: both odd / even mix
+    ((960, 540), (400, 300), 2, 1, 0, True, (0, 0, 0, 0)),      # BICUBIC non-dyadic: wave-per-tile kernel with host tables
+    ((1280, 720), (214, 120), 3, 2, 0, True, (0, 0, 0, 0)),     # AREA ~6 x 6 float weights
+    ((1280, 720), (320, 180), 3, 2, 0, True, (0, 0, 0, 0)),     # AREA 4 x 4: box kernel
+    ((640, 360), (1280, 720), 3, 1, 1, True, (0, 0, 0, 0)),     # AREA up-scale
+    ((640, 360), (1280, 720), 1, 1, 1, False, (0, 0, 0, 0)),    # BILINEAR 1 : 2 streaming
+    ((960, 540), (320, 180), 0, 1, 0, False, (0, 0, 0, 0)),     # NEAREST point kernel
+    ((960, 540), (300, 200), 1, 3, 1, False, (101, 51, 901, 451)),  # crop with an odd origin, NV12 output
+    ((960, 540), (0, 0), 0, 6, 1, True, (100, 50, 500, 350)),   # crop only, HSV
+]
+
+
+@pytest.mark.parametrize("src,dst,rt,fourcc,planes,norm,crop", CASES)
+def test_table_matches_batch_and_oracle(vpp, oracle, src, dst, rt, fourcc, planes, norm, crop):
+    import tensor_stream as ts
+    w, h = src
+    pitch = (w + 63) // 64 * 64
+    n = N_FRAMES
+    ys, uvs = _pool(w, h, pitch, n, seed=w + dst[0] + rt)
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+    want = vpp.convert_batch(ys, uvs, fp, width=w)
+    tab = vpp.make_table(ys, uvs, fp, width=w)
+    got = vpp.run_table(tab)
+    torch.cuda.synchronize()
+    assert got.data_ptr() != want.data_ptr()
+    for f in range(n):
+        assert torch.equal(got[f].view(torch.uint8), want[f].view(torch.uint8)), f
+    for f in (0, 127, 128, n - 1):
+        _check(oracle, ys, uvs, got, f, w, crop, dst, rt, fourcc, planes, norm)
+    vpp.free_table(tab)
+
+
+def test_runs_inside_the_table_and_replaced_entries(vpp, oracle):
+    import tensor_stream as ts
+    from tensor_stream import _native as N
+    w, h, pitch, n = 640, 360, 640, 200
+    ys, uvs = _pool(w, h, pitch, n, seed=9)
+    fp = ts.FrameParameters(width=320, height=180, resize_type=1, pixel_format=2, planes_pos=0, normalization=True)
+    tab = vpp.make_table(ys, uvs, fp, width=w)
+    out = tab["out"]
+    out.zero_()
+    vpp.run_table(tab, first=37, n=150)  # a run that starts and ends inside the table: one 150-frame launch
+    torch.cuda.synchronize()
+    assert not out[36].any() and not out[187].any()
+    for f in (37, 100, 186):
+        _check(oracle, ys, uvs, out, f, w, (0, 0, 0, 0), (320, 180), 1, 2, 0, True)
+    # replace entries 10 .. 12 by frames 150 .. 152 writing into outputs 0 .. 2, on the stream the conversion then runs on
+    stream = torch.cuda.current_stream().cuda_stream
+    fr = (N.NV12 * 3)(*[vpp._frame(ys[150 + i], uvs[150 + i], w, None) for i in range(3)])
+    outs = (ctypes.c_void_p * 3)(*[out[i].data_ptr() for i in range(3)])
+    N.check(vpp._lib.tsvpp_table_set(tab["handle"], 10, 3, fr, outs, stream))
+    vpp.run_table(tab, first=10, n=3)
+    torch.cuda.synchronize()
+    for i in range(3):
+        ref, _, _ = oracle.convert(ys[150 + i].cpu().numpy(), uvs[150 + i].cpu().numpy(), dst=(320, 180), resize_type=1, fourcc=2, planes=0, normalization=True,
+                                   nthreads=8, width=w)
+        assert np.array_equal(out[i].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), i
+    # another request over the same table: the parameters belong to the call
+    fp2 = ts.FrameParameters(width=0, height=0, crop_coords=(64, 32, 576, 328), resize_type=0, pixel_format=1, planes_pos=1, normalization=False)
+    out2 = vpp._alloc(fp2.parameters, w, h, n)
+    tab2 = vpp.make_table(ys, uvs, fp2, out=out2, width=w)
+    vpp.run_table(tab2)
+    torch.cuda.synchronize()
+    for f in (0, 199):
+        _check(oracle, ys, uvs, out2, f, w, (64, 32, 576, 328), (0, 0), 0, 1, 1, False)
+    vpp.free_table(tab)
+    vpp.free_table(tab2)
+
+
+@pytest.mark.parametrize("fourcc,dst", [(4, (320, 180)), (5, (300, 200)), (4, (0, 0)), (5, (426, 240))])
+def test_two_pass_formats_over_a_table(vpp, oracle, fourcc, dst):
+    """UYVY / YUV444: single-pass where the streaming kernel takes them (640x360 -> 426x240 is 3 : 2 ... not exactly: two passes), two passes otherwise --
+    through the table's host mirror in launches of <= 128 frames."""
+    import tensor_stream as ts
+    w, h, pitch, n = 640, 360, 640, 140
+    ys, uvs = _pool(w, h, pitch, n, seed=fourcc)
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=1, pixel_format=fourcc, planes_pos=1, normalization=False)
+    tab = vpp.make_table(ys, uvs, fp, width=w)
+    got = vpp.run_table(tab)
+    torch.cuda.synchronize()
+    for f in (0, 127, 128, n - 1):
+        _check(oracle, ys, uvs, got, f, w, (0, 0, 0, 0), dst, 1, fourcc, 1, False)
+    vpp.free_table(tab)
+
+
+def test_error_paths(vpp):
+    import tensor_stream as ts
+    from tensor_stream import _native as N
+    L = vpp._lib
+    w, h, n = 64, 32, 4
+    ys, uvs = _pool(w, h, w, n, seed=1)
+    fp = ts.FrameParameters(width=32, height=16, resize_type=1, pixel_format=1, planes_pos=0, normalization=False)
+    out = vpp._alloc(fp.parameters, w, h, n)
+    h_tab = ctypes.c_void_p()
+    assert L.tsvpp_table_create(vpp._ctx, 0, ctypes.byref(h_tab)) == -3            # capacity < 1
+    assert L.tsvpp_table_create(vpp._ctx, 8, ctypes.byref(h_tab)) == 0
+    stream = torch.cuda.current_stream().cuda_stream
+    fr = (N.NV12 * n)(*[vpp._frame(ys[i], uvs[i], w, None) for i in range(n)])
+    outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+    assert L.tsvpp_table_set(h_tab, 6, n, fr, outs, stream) == -3                  # past the capacity
+    assert L.tsvpp_table_set(h_tab, 0, n, fr, outs, stream) == 0
+    assert L.tsvpp_convert_table(vpp._ctx, h_tab, 0, 5, ctypes.byref(fp.parameters), stream) == -3   # entry 4 was never set
+    assert L.tsvpp_convert_table(vpp._ctx, h_tab, 2, 7, ctypes.byref(fp.parameters), stream) == -3   # past the capacity
+    assert L.tsvpp_convert_table(vpp._ctx, h_tab, 0, 0, ctypes.byref(fp.parameters), stream) == 0    # nothing to do
+    ys2, uvs2 = _pool(128, 32, 128, 1, seed=2)                                                       # another geometry: one per table
+    fr2 = (N.NV12 * 1)(vpp._frame(ys2[0], uvs2[0], 128, None))
+    assert L.tsvpp_table_set(h_tab, 4, 1, fr2, outs, stream) == -2
+    bad = ts.FrameParameters(width=31, height=16, resize_type=1, pixel_format=1, planes_pos=0, normalization=False)
+    assert L.tsvpp_convert_table(vpp._ctx, h_tab, 0, n, ctypes.byref(bad.parameters), stream) == -2  # odd output width: as tsvpp_convert_batch
+    assert L.tsvpp_convert_table(vpp._ctx, h_tab, 0, n, ctypes.byref(fp.parameters), stream) == 0
+    torch.cuda.synchronize()
+    L.tsvpp_table_destroy(h_tab)

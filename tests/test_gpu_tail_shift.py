@@ -45,7 +45,7 @@ def frame():
 @pytest.mark.parametrize("fourcc,planes,norm", FLAVOURS)
 @pytest.mark.parametrize("dst,rt,kernel", [
     ((854, 480), NEAREST, "point"), ((1366, 768), NEAREST, "point"), ((270, 270), NEAREST, "point"),
-    ((854, 480), BILINEAR, "vpp_bilinear_kernel"), ((1366, 768), BILINEAR, "vpp_bilinear_kernel"), ((270, 270), BILINEAR, "gather"),
+    ((854, 480), BILINEAR, "vpp_bilinear_kernel"), ((1366, 768), BILINEAR, "vpp_bilinear_kernel"), ((270, 270), BILINEAR, "bilinear_rows"),
     ((854, 480), BICUBIC, "bicubic_cols"), ((1366, 768), BICUBIC, "bicubic_cols"), ((270, 270), BICUBIC, "sparse"),
     ((854, 480), AREA, "area_direct_float"), ((1366, 768), AREA, "areaf"), ((270, 270), AREA, "area_cols"), ((266, 266), AREA, "area_stream"),
     ((418, 418), AREA, "area_cols"), ((642, 362), AREA, None), ((1082, 608), AREA, None), ((1082, 608), BILINEAR, None), ((1082, 608), BICUBIC, None),

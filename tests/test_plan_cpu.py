@@ -64,8 +64,10 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
 
 @pytest.mark.parametrize("src,dst,rt,kernel", [
     ((1920, 1080), (0, 0), N, "vpp_color_kernel"),                       # C2: no resize
-    ((3840, 2160), (1280, 720), C, "vpp_point_kernel<PK_BICUBIC0"),      # C4: every cubic weight is zero
+    ((3840, 2160), (1280, 720), C, "vpp_point_kernel<PK_BICUBIC0"),         # C4's geometry, fp32 output: every cubic weight is zero -> LDS point kernel
     ((3840, 2160), (1280, 720), B, "vpp_point_kernel<PK_BILINEAR0"),
+    ((1960, 1120), (280, 160), B, "vpp_point_kernel<PK_BILINEAR0"),         # 7 : 1: all weights zero, no streaming instance -> LDS point kernel
+    ((3840, 2160), (480, 270), N, "vpp_point_kernel<PK_NEAREST"),           # 8 : 1
     ((1920, 1080), (1280, 720), N, "vpp_point_kernel<PK_NEAREST"),
     ((3840, 2160), (640, 360), A, "vpp_area_box_kernel<6,1"),            # C5: 6 x 6 box from contiguous dword runs
     ((3840, 2160), (960, 540), A, "vpp_area_box_kernel<4,1"),            # 4 x 4
@@ -111,6 +113,16 @@ def test_c3_crop_folds_into_pointers_and_the_sparse_bilinear_streams_its_rows():
     # a pitch that is no multiple of 16 (rows with different misalignments), unaligned outputs: byte gathers
     assert plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=1924)["kernel"].startswith("vpp_fused_gather_kernel")
     assert plan((1920, 1080), (256, 256), B, fourcc=RGB24, crop=(0, 0, 1280, 720), pitch=2048, aligned_outputs=False)["kernel"] == "vpp_fused_gather_kernel<MODE,OUT,false>"
+
+
+def test_c4_runs_the_streaming_point_sampler():
+    """BASELINE config C4: 4K -> 720p BICUBIC -> BGR24 MERGED uint8: exact 3 : 1, every cubic weight zero -> vpp_point_rn.hip (uint8 flavours; fp32 stays on the LDS kernel)."""
+    p = plan((3840, 2160), (1280, 720), C, fourcc=BGR24, planes=1, norm=False, pitch=3840)
+    assert p["kernel"] == "vpp_point_rn_kernel<OUT,3:1,centre>" and p["shape"] == "64x4" and p["tiles"] == "3x45", p
+    assert plan((3840, 2160), (1280, 720), N, fourcc=RGB24, planes=0, norm=False, pitch=3840)["kernel"] == "vpp_point_rn_kernel<OUT,3:1,nearest>"
+    assert plan((3840, 2160), (960, 540), N, fourcc=RGB24, planes=1, norm=False, pitch=3840)["kernel"] == "vpp_point_rn_kernel<OUT,4:1,nearest>"
+    assert plan((1920, 1080), (384, 216), B, fourcc=RGB24, planes=1, norm=False, pitch=2048)["kernel"] == "vpp_point_rn_kernel<OUT,5:1,centre>"
+    assert plan((3840, 2160), (1280, 720), C, fourcc=BGR24, planes=1, norm=False, pitch=3842)["kernel"].startswith("vpp_point_kernel")  # planes not dword-aligned
 
 
 def test_small_outputs_keep_two_row_thread_tiles():
@@ -171,8 +183,9 @@ def test_widths_4k_plus_2_stay_on_the_fast_kernels_and_unaligned_outputs_gather(
 
 
 def test_large_footprints_fall_back_to_smaller_workgroups_or_gathers():
-    p = plan((7680, 4320), (2560, 1440), C)            # 8K bicubic at ratio 3 (all weights zero -> point kernel)
-    assert p["kernel"].startswith("vpp_point_kernel")
+    p = plan((7680, 4320), (2560, 1440), C)            # 8K bicubic at ratio 3 (all weights zero -> point kernel; uint8: the streaming one, no footprint at all)
+    assert p["kernel"].startswith("vpp_point_kernel") and p["lds"] <= 40 * 1024
+    assert plan((7680, 4320), (2560, 1440), C, norm=False)["kernel"].startswith("vpp_point_rn_kernel")
     p = plan((7680, 4320), (2800, 1576), C)            # 2.74: staged bicubic must fit the 40 KiB LDS budget
     assert p["lds"] <= 40 * 1024 and p["kernel"].startswith("vpp_bicubic_cols_kernel")
 

@@ -4,6 +4,11 @@
 # heights, direct-kernel thresholds, workgroup shapes, tile orders, store policies, geometry tables, the streaming 3:2 / 2:1 kernel incl. its
 # single-pass UYVY / YUV444) must stay bit-exact.  KNOBS="..." (newline-separated) overrides the list, TESTS="files" the suite (default: tests).
 DEFAULT="TSVPP_FORCE_GATHER=1
+TSVPP_BILINEAR_ROWS=0
+TSVPP_BILINEAR_ROWS=2
+TSVPP_BILINEAR_ROWS_WAVES=1
+TSVPP_POINT_RN=0
+TSVPP_POINT_RN=2
 TSVPP_DMA=0
 TSVPP_BILINEAR_INT=0
 TSVPP_BILINEAR_INT=2
