@@ -412,7 +412,7 @@ def spawn(args, argv):
                "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         rc, out = p.returncode, p.stdout
-        if rc == 0 or '{"metric"' in out:
+        if rc == 0 or '{"metric"' in out or '{"error"' in out:  # (an error line is an answer too: set-up failed on some rank, retrying cannot help)
             break
         print(f"bench.py: launch attempt {attempt + 1} of {args.gpus} ranks exited {rc} without a line; retrying on another port", file=sys.stderr, flush=True)
     sys.stdout.write(out)
@@ -666,34 +666,128 @@ def run(args):
     dist = None
     out_fd = None
     backend = None
-    # world == 1 still takes the collective path under torch.distributed.run (`--nproc-per-node=1`) or TSVPP_BENCH_FORCE_DIST=1:
-    # the RCCL plumbing is exercised on a one-GPU box (tests/test_bench_gpu.py) before an 8-GPU node ever sees it
-    if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1" or "TORCHELASTIC_RUN_ID" in os.environ:
-        # RCCL prints a version banner on stdout: keep stdout for the ONE JSON line (everything else goes to stderr)
-        sys.stdout.flush()
-        out_fd = os.dup(1)
-        os.dup2(2, 1)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+    # ---- set-up, time-boxed.  The driver's SCALE run is the first time this code meets 8 real GPUs: a rank that dies or hangs in ANY set-up step
+    # (rendezvous, RCCL communicator, NUMA pinning, the 2.6 GiB buffer fill, the coefficient broadcast) must end the job with ONE {"error": ...} line and a non-zero exit
+    # code, never with seven ranks parked in a barrier.  Every step is timed and logged to stderr with the rank; the per-rank totals travel in the line (`setup_s`).
+    setup_limit = float(os.environ.get("TSVPP_BENCH_SETUP_TIMEOUT", "300"))
+    setup_log = []
+
+    def log(msg):
+        print(f"[bench.py rank {rank}/{world}] {msg}", file=sys.stderr, flush=True)
+
+    def fail_line(why, code=3):
+        """The job cannot be measured: rank 0 says so on stdout (one JSON line), every rank on stderr; exit without waiting for anybody."""
+        log(f"SET-UP FAILED: {why}")
+        if rank == 0:
+            line = json.dumps({"error": f"set-up failed: {why}", "metric": metric_name(name, args.resize), "value": None, "unit": "frames/s", "n_gpus": world,
+                               "steps": args.steps, "warmup": args.warmup, "setup_log": setup_log})
+            try:
+                os.write(out_fd if out_fd is not None else 1, (line + "\n").encode())
+            except OSError:
+                pass
+        os._exit(code)
+
+    import signal
+    import threading
+    # rank 0 reports first (it owns the line); the other ranks give it five seconds, then leave too
+    watchdog = threading.Timer(setup_limit + (0.0 if rank == 0 else 5.0),
+                               lambda: fail_line(f"rank {rank} did not finish set-up within {setup_limit:.0f} s (last step: {setup_log[-1][0] if setup_log else 'none'})"))
+    watchdog.daemon = True
+    watchdog.start()
+    # a rank that dies outright makes the launcher SIGTERM the others: rank 0 still says why there is no measurement
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, lambda *_: fail_line("terminated by the launcher during set-up (another rank died: see its stderr)", code=4))
+    except ValueError:  # not the main thread (in-process tests)
+        pass
+
+    def step_of(label, fn):
+        t_s = time.perf_counter()
+        setup_log.append([label, None])
+        log(f"set-up: {label} ...")
+        r = fn()
+        setup_log[-1][1] = round(time.perf_counter() - t_s, 3)
+        log(f"set-up: {label} done in {setup_log[-1][1]:.3f} s")
+        return r
+
+    inject = os.environ.get("TSVPP_BENCH_FAIL", "")  # tests: "<rank>:<step>:<raise|hang|exit>" makes that rank fail in that set-up step
+
+    def injected(label):
+        if not inject:
+            return
+        r_, s_, how = inject.split(":")
+        if int(r_) == rank and s_ == label:
+            if how == "hang":
+                time.sleep(10 * setup_limit)
+            if how == "exit":
+                os._exit(9)
+            raise RuntimeError(f"injected failure in {label}")
+
+    t_setup = time.perf_counter()
+    eng = None
+    affinity = None
+    setup_error = None
+    try:
+        # world == 1 still takes the collective path under torch.distributed.run (`--nproc-per-node=1`) or TSVPP_BENCH_FORCE_DIST=1:
+        # the RCCL plumbing is exercised on a one-GPU box (tests/test_bench_gpu.py) before an 8-GPU node ever sees it
+        if world > 1 or os.environ.get("TSVPP_BENCH_FORCE_DIST") == "1" or "TORCHELASTIC_RUN_ID" in os.environ:
+            # RCCL prints a version banner on stdout: keep stdout for the ONE JSON line (everything else goes to stderr)
+            sys.stdout.flush()
+            out_fd = os.dup(1)
+            os.dup2(2, 1)
+            import datetime
+            import torch.distributed as dist_mod
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            tmo = datetime.timedelta(seconds=max(30.0, setup_limit))
+
+            def init_pg():
+                injected("rendezvous")
+                if stub:
+                    dist_mod.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+                else:
+                    import torch
+                    torch.cuda.set_device(local)
+                    dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=tmo)
+            backend = "gloo" if stub else "nccl"
+            step_of("rendezvous", init_pg)
+            dist = dist_mod
         if stub:
-            backend = "gloo"
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            def make_stub():
+                injected("engine")
+                return StubEngine(args, spec, rank)
+            eng = step_of("engine", make_stub)
         else:
             import torch
-            backend = "nccl"
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    affinity = None
-    if stub:
-        eng = StubEngine(args, spec, rank)
-    else:
-        import torch
-        dev = local if dist is not None else 0
-        torch.cuda.set_device(dev)
-        if dist is not None and not args.no_pin:
-            affinity = pin_to_gpu_numa(dev)
-        eng = GpuEngine(args, spec, rank, dev, dist)
+            dev = local if dist is not None else 0
+            torch.cuda.set_device(dev)
+            if dist is not None and not args.no_pin:
+                affinity = step_of("numa-pin", lambda: pin_to_gpu_numa(dev))
+
+            def make_engine():
+                injected("engine")
+                return GpuEngine(args, spec, rank, dev, dist)  # context, coefficient broadcast (the one collective), buffer fill, descriptor tables
+            eng = step_of("engine", make_engine)
+    except Exception as e:  # noqa: BLE001 -- anything: the other ranks must learn about it
+        setup_error = f"rank {rank}: {type(e).__name__}: {e}"
+        log(f"set-up error: {setup_error}")
+    # every rank tells every rank whether it is ready: a failed rank takes part in this ONE collective (if it still can) so that the others leave together
+    if dist is not None:
+        try:
+            import torch
+            flag = torch.tensor([0.0 if setup_error else 1.0], dtype=torch.float64, device="cpu" if stub else "cuda")
+            step_of("ready-check", lambda: dist.all_reduce(flag, op=dist.ReduceOp.MIN))
+            if flag.item() < 0.5 and not setup_error:
+                setup_error = "another rank failed its set-up (see its stderr)"
+        except Exception as e:  # noqa: BLE001
+            setup_error = setup_error or f"rank {rank}: ready-check failed: {type(e).__name__}: {e}"
+    if setup_error:
+        fail_line(setup_error)
+    watchdog.cancel()
+    if old_term is not None:
+        signal.signal(signal.SIGTERM, old_term)
+    setup_s = round(time.perf_counter() - t_setup, 3)
+    log(f"set-up complete in {setup_s:.3f} s")
 
     B = args.batch
 
@@ -785,6 +879,7 @@ def run(args):
         issue = gather(mine_reps[med][2] * 1e3 / args.steps)
         per_rank = {"min_frames_per_s": round(min(rates), 1), "max_frames_per_s": round(max(rates), 1),
                     "frames_per_s": [round(x, 1) for x in rates], "host_issue_ms_per_step": [round(x, 4) for x in issue],
+                    "setup_s": [round(x, 3) for x in gather(setup_s)], "rank0_setup_steps": setup_log,
                     "backend": backend, "rank0_affinity": affinity}
 
     # Side measurements (outside the timed region, every rank takes part, same barrier / max-over-ranks bracket): the
@@ -872,7 +967,7 @@ def run(args):
             "timing": {"repeats": len(reps), "reported": "median repeat (max over ranks per repeat)",
                        "total_timed_steps": total_steps, "mean_ms_per_step": round(mean_wall * 1e3, 4),
                        "max_ms_per_step": round(max(r[0] for r in reps) * 1e3 / args.steps, 4),
-                       "warmup_steps_total": args.warmup + extra, "warmup_ms": args.warmup_ms,
+                       "warmup_steps_total": args.warmup + extra, "warmup_ms": args.warmup_ms, "setup_s": setup_s,
                        "repeats_ms_per_step": [round(r[0] * 1e3 / args.steps, 4) for r in reps],
                        "repeats_avg_launch_ms": [round(r[1] / (args.steps * eng.launches_per_step), 5) for r in reps]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

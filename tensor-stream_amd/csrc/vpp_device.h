@@ -343,14 +343,18 @@ template <> struct OutT<O_HSV_F32> { using type = float; };
 template <int OUT> constexpr bool kLumaOnly = (OUT == O_Y800_U8 || OUT == O_Y800_F32);
 
 // Per-block chroma terms: t0 / t2 are added to luma for the first / third stored channel
-// (R,B or B,R when swapped), tg for green.
+// (R,B or B,R when swapped), tg for green.  The operation tree is the reference's AS COMPILED (reference src/ColorConversion.cu:25-36 under nvcc's default
+// -fmad=true; oracle/vpp_oracle.c, CT_NVCC -- the fusion rule the resize goldens pin, applied to this stage):
+//     RVal = fma(1.596, V - 128, 0.5), BVal = fma(2.018, U - 128, 0.5)                      (single-use products: fused)
+//     GVal = fma(-0.813, V - 128, -(0.391 (U - 128))) + 0.5                                 (the subtraction's left product fused, the right one rounded)
+// and the luma product Y' = max(0, Y - 16) * 1.164 stays a rounded product (it feeds three sums).  R and B do not depend on the contraction for any
+// (Y, U, V); G differs from the plain-IEEE tree of rounds 1-4 by one on 36 of the 2^24 triples (tests/test_oracle_contract.py).
 __device__ __forceinline__ void chroma_terms(float Uf, float Vf, const tsvpp_coeffs &k, int swap_rb, float &t0, float &tg, float &t2) {
     f2 uv = { Uf, Vf };
     uv = uv - (f2){ k.c_offset, k.c_offset };
-    f2 br = uv * (f2){ k.u_to_b, k.v_to_r };
-    br = br + (f2){ k.round_bias, k.round_bias }; // { 2.018 (U-128) + .5, 1.596 (V-128) + .5 }
-    f2 g = uv * (f2){ k.u_to_g, k.v_to_g };        // u_to_g < 0: g.y + g.x == -0.813 (V-128) - 0.391 (U-128)
-    float gv = g.y + g.x;
+    const f2 br = __builtin_elementwise_fma(uv, (f2){ k.u_to_b, k.v_to_r }, (f2){ k.round_bias, k.round_bias }); // { 2.018 (U-128) + .5, 1.596 (V-128) + .5 }
+    const float gu = uv.x * k.u_to_g;                    // u_to_g < 0: -(0.391 (U-128)), rounded
+    const float gv = __builtin_fmaf(uv.y, k.v_to_g, gu); // -0.813 (V-128) - 0.391 (U-128): ONE rounding of the left product's sum
     tg = gv + k.round_bias;
     t0 = swap_rb ? br.x : br.y;
     t2 = swap_rb ? br.y : br.x;

@@ -247,3 +247,34 @@ def test_torchrun_world1_takes_the_collective_path_on_gloo():
     res = _line(p.stdout)
     assert res["n_gpus"] == 1 and res["per_rank"]["backend"] == "gloo" and len(res["per_rank"]["host_issue_ms_per_step"]) == 1
     assert res["timing"]["total_timed_steps"] == res["timing"]["repeats"] * 4
+
+
+@pytest.mark.parametrize("how,step", [("raise", "engine"), ("hang", "engine"), ("exit", "engine"), ("raise", "rendezvous")])
+def test_a_rank_that_fails_its_setup_ends_the_job_with_one_error_line(how, step):
+    """world size 8 on gloo, rank 5 fails in a set-up step (an exception, a hang, an abrupt exit): the job must end within a minute
+    with ONE {"error": ...} line from rank 0 and a non-zero exit code -- never with seven ranks parked in a barrier."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TSVPP_BENCH_STUB="1", TSVPP_BENCH_FAIL=f"5:{step}:{how}", TSVPP_BENCH_SETUP_TIMEOUT="15")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    took = time.time() - t0
+    assert p.returncode != 0 and took < 90, (p.returncode, took, p.stderr[-1500:])
+    assert '{"metric"' not in p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"error"')]
+    assert len(lines) == 1, (p.stdout[-500:], p.stderr[-1500:])
+    err = json.loads(lines[0])
+    assert err["value"] is None and err["n_gpus"] == 8 and "set-up failed" in err["error"]
+    assert "[bench.py rank 5/8]" in p.stderr  # every step of every rank is logged with its rank
+
+
+def test_setup_times_travel_in_the_line():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSVPP_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    assert len(res["per_rank"]["setup_s"]) == 2 and all(x >= 0 for x in res["per_rank"]["setup_s"]) and res["timing"]["setup_s"] >= 0
+    steps = [s[0] for s in res["per_rank"]["rank0_setup_steps"]]
+    assert steps[:2] == ["rendezvous", "engine"] and "ready-check" in steps
+    assert "set-up: rendezvous done" in p.stderr and "[bench.py rank 1/2]" in p.stderr

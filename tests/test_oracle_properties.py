@@ -85,9 +85,16 @@ def test_upscale_area_runs_bilinear_variant(oracle):
     assert np.array_equal(a[0::2, 0::2], y)   # fx = (j+1) - (x+1)/0.5 <= 0 at even j -> weight 0 -> source pixel
 
 
+def _fma32(a, b, c):
+    """fma(a, b, c) of float32 operands with ONE rounding, in numpy: every product here is a 24-bit constant times an integer below 2^8 and every addend has
+    at most 24 significant bits within 2^-26 .. 2^9 of it, so the float64 product and sum are EXACT and the single conversion to float32 is the fma's rounding."""
+    return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+
 def test_colour_matches_independent_numpy_restatement_on_all_triples(oracle):
-    """Second, independent restatement of src/ColorConversion.cu:23-38 in numpy float32 ops
-    (numpy never fuses), over all 2^24 (Y,U,V) triples."""
+    """Second, independent restatement of src/ColorConversion.cu:23-38 in numpy float32 ops over all 2^24 (Y,U,V) triples, with the operation tree of the
+    reference AS COMPILED (oracle/vpp_oracle.c, CT_NVCC): the chroma terms' single-use products fused, the luma product and the final sums plain.  numpy
+    never fuses: the two fused operations are spelt out (_fma32)."""
     y, uv = coverage_frame()
     out, _, _ = oracle.convert(y, uv, fourcc=oracle.RGB24, planes=oracle.PLANAR, nthreads=8)
     out = out.reshape(3, 4096, 4096)
@@ -95,10 +102,11 @@ def test_colour_matches_independent_numpy_restatement_on_all_triples(oracle):
     Y = y.astype(f)
     U = np.repeat(np.repeat(uv[:, 0::2], 2, 0), 2, 1).astype(f) - f(128)
     V = np.repeat(np.repeat(uv[:, 1::2], 2, 0), 2, 1).astype(f) - f(128)
+    half = np.full_like(Y, f(0.5))
     yv = np.maximum(f(0), Y - f(16)) * f(1.163999557)
-    R = (yv + (f(1.5959997177) * V + f(0.5))).astype(np.int32).clip(0, 255)
-    B = (yv + (f(2.017999649) * U + f(0.5))).astype(np.int32).clip(0, 255)
-    G = (yv + ((f(-0.812999725) * V - f(0.390999794) * U) + f(0.5))).astype(np.int32).clip(0, 255)
+    R = (yv + _fma32(V, f(1.5959997177), half)).astype(np.int32).clip(0, 255)
+    B = (yv + _fma32(U, f(2.017999649), half)).astype(np.int32).clip(0, 255)
+    G = (yv + (_fma32(V, f(-0.812999725), -(f(0.390999794) * U)) + f(0.5))).astype(np.int32).clip(0, 255)
     assert np.array_equal(out[0], R.astype(np.uint8))
     assert np.array_equal(out[1], G.astype(np.uint8))
     assert np.array_equal(out[2], B.astype(np.uint8))
