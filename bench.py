@@ -54,13 +54,17 @@ WORKLOADS = {
     "c4": (3840, 2160, 3840, (0, 0, 0, 0), (1280, 720), "BICUBIC", "BGR24", "MERGED", False),
     "c5": (3840, 2160, 3840, (0, 0, 0, 0), (640, 360), "AREA", "BGR24", "PLANAR", True),
 }
+# frames per step and "out of a persistent frame table" when --batch is not given.  C3 moves 1.8 MB per frame and C4 6.9 MB: their 64-frame launches (113 / 442 MB) run at
+# 0.64 / 0.64 of the roofline on moved bytes, 0.72 / 0.67 from 512 / 256 frames on (profiles/r05_table_ab.txt, r05_c4_shapes.txt); the headline and the other
+# configurations gain nothing (or lose: 1024-frame launches of the headline 0.775 -> 0.711) and keep 64
+DEFAULT_BATCH = {"c3": (512, True), "c4": (256, True)}
 RESIZE = {"NEAREST": 0, "BILINEAR": 1, "BICUBIC": 2, "AREA": 3}
 FOURCC = {"Y800": 0, "RGB24": 1, "BGR24": 2, "NV12": 3, "UYVY": 4, "YUV444": 5, "HSV": 6}
 PLANES = {"PLANAR": 0, "MERGED": 1}
 # sources whose hash stamps a PMC traffic entry (tools/traffic_json.py writes it, lookup_traffic checks it)
 KERNEL_SOURCES = ["tensor-stream_amd/csrc/vpp_kernels.hip", "tensor-stream_amd/csrc/vpp_select.hip", "tensor-stream_amd/csrc/vpp_bicubic_r32.hip", "tensor-stream_amd/csrc/vpp_bicubic_r32_core.h", "tensor-stream_amd/csrc/vpp_r32_store.h", "tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_bicubic_int.hip", "tensor-stream_amd/csrc/vpp_bilinear.hip", "tensor-stream_amd/csrc/vpp_bilinear_r32.hip",
                   "tensor-stream_amd/csrc/vpp_area_box.hip", "tensor-stream_amd/csrc/vpp_area_stream.hip", "tensor-stream_amd/csrc/vpp_bicubic_cols.hip", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h",
-                  "tensor-stream_amd/csrc/vpp_formats.hip", "tensor-stream_amd/csrc/tsvpp_api.cpp"]
+                  "tensor-stream_amd/csrc/vpp_formats.hip", "tensor-stream_amd/csrc/tsvpp_api.cpp", "tensor-stream_amd/csrc/vpp_bilinear_rows.hip", "tensor-stream_amd/csrc/vpp_point_rn.hip"]
 
 
 def roi_and_dst(src_w, src_h, crop, dst):
@@ -255,7 +259,8 @@ def latency_leg(spec, iters=2000):
 
 
 _SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
-_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear_up2", "vpp_bilinear_up2.hip"), ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
+_KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear_up2", "vpp_bilinear_up2.hip"), ("vpp_bilinear_rows", "vpp_bilinear_rows.hip"), ("vpp_point_rn", "vpp_point_rn.hip"),
+                 ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
                  ("vpp_bicubic_cols", "vpp_bicubic_cols.hip"), ("vpp_area_box", "vpp_area_box.hip"), ("vpp_area_stream", "vpp_area_stream.hip"),
                  ("fmt_", "vpp_formats.hip")]
 
@@ -267,7 +272,7 @@ def kernel_source_files(kernel=None):
         return list(KERNEL_SOURCES)
     k = kernel.split("::")[-1]
     unit = next((f for prefix, f in _KERNEL_FILES if k.startswith(prefix)), "vpp_kernels.hip")
-    extra = {"vpp_bicubic_r32.hip": ["vpp_bicubic_r32_core.h", "vpp_r32_store.h"], "vpp_bilinear_r32.hip": ["vpp_r32_store.h"],
+    extra = {"vpp_bicubic_r32.hip": ["vpp_bicubic_r32_core.h", "vpp_r32_store.h"], "vpp_bilinear_r32.hip": ["vpp_r32_store.h"], "vpp_point_rn.hip": ["vpp_r32_store.h"],
              "vpp_bilinear_up2.hip": ["vpp_bilinear_up2_core.h", "vpp_bicubic_r32_core.h", "vpp_r32_store.h", "vpp_up2.h"]}.get(unit, [])
     return ["tensor-stream_amd/csrc/" + f for f in [unit] + extra] + _SHARED_SOURCES
 
@@ -335,7 +340,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is run this many times and the median is reported; "
                     "0 = max(5, ceil(400 / steps)): SURVEY.md 8(d) asks for >= 200 timed iterations and a median of 5; 400 keep the clock ramp of the first ~25 ms out of the median")
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (one launch per MAX_LAUNCH = 128 frames: tsvpp.h TSVPP_MAX_BATCH)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (one launch per MAX_LAUNCH = 128 frames: tsvpp.h TSVPP_MAX_BATCH; with --table up to 1024 per launch).  "
+                    "Default: 64 -- except the small-frame BASELINE configurations C3 (512) and C4 (256), which run out of a persistent frame table (DEFAULT_BATCH)")
     ap.add_argument("--table", action="store_true", help="register every buffer set ONCE in a persistent device-resident frame table (tsvpp_table_*) and convert it with "
                     "tsvpp_convert_table: launches of up to 1024 frames (--batch may then exceed 128 per launch); the pools of a real pipeline come round again the same way")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
@@ -421,9 +427,10 @@ def spawn(args, argv):
 
 
 class _StubWork:
-    def __init__(self, args):
-        self.frames_per_launch = float(min(args.batch, MAX_LAUNCH))
-        self.launches_per_step = (args.batch + MAX_LAUNCH - 1) // MAX_LAUNCH
+    def __init__(self, args, batch=None):
+        self.B = batch or args.batch
+        self.frames_per_launch = float(min(self.B, MAX_LAUNCH))
+        self.launches_per_step = (self.B + MAX_LAUNCH - 1) // MAX_LAUNCH
 
     def issue(self, i, stream):
         time.sleep(0.0005)
@@ -455,8 +462,8 @@ class StubEngine:
         dt = time.perf_counter() - t0
         return dt * 1e3, dt  # "device" ms, host issue s
 
-    def side_work(self, spec, sets=2):
-        return _StubWork(self.args)
+    def side_work(self, spec, sets=2, batch=None, table=False):
+        return _StubWork(self.args, batch)
 
     def close(self):
         pass
@@ -623,9 +630,9 @@ class GpuEngine:
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1), host_issue
 
-    def side_work(self, spec, sets=2):
+    def side_work(self, spec, sets=2, batch=None, table=False):
         """A second workload on the same context (other resize types of the headline, the 4K configurations): its own buffers."""
-        return GpuWork(self, spec, self.args.batch, sets, 4321 + self.rank)
+        return GpuWork(self, spec, batch or self.args.batch, sets, 4321 + self.rank, table=table)
 
     def close(self):
         self.vpp.Close()
@@ -663,6 +670,9 @@ def run(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     spec, name = resolve_spec(args)
     src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+    if args.batch is None:  # per-workload default (DEFAULT_BATCH); an explicit --batch is taken as given
+        args.batch, tbl = DEFAULT_BATCH.get(name if not (args.resize or args.per_call or args.graph) else "", (64, False))
+        args.table = args.table or tbl
     dist = None
     out_fd = None
     backend = None
@@ -897,7 +907,8 @@ def run(args):
     def side(sp, steps=20, wl_name=None):
         w, err = None, None
         try:
-            w = eng.side_work(sp)
+            sb, stab = DEFAULT_BATCH.get(wl_name, (None, False)) if wl_name else (None, False)
+            w = eng.side_work(sp, batch=sb, table=stab)
         except Exception as e:
             err = f"{type(e).__name__}: {e}"
         if not all_ranks_ok(w is not None):
@@ -915,7 +926,7 @@ def run(args):
             (sw, sdev, _), _ = region(steps, 0, w)
             bpf = bytes_of(sp)
             ms = sdev / (steps * w.launches_per_step)
-            r = {"frames_per_s": round(B * steps * world / sw, 1), "avg_launch_ms": round(ms, 5),
+            r = {"frames_per_s": round(w.B * steps * world / sw, 1), "avg_launch_ms": round(ms, 5), "frames_per_launch": w.frames_per_launch,
                  "hbm_frac": round(bpf * w.frames_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if rank == 0 and wl_name:  # sparse samplers are priced on the bytes they move (see roofline.frac_basis), never > 1
                 tbs = touched_bytes(sp)

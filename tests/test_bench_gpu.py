@@ -14,6 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+# fractions of 8 TB/s on algorithmic bytes (headline and its other resize types), frames/s for the 4K configurations (their fraction's basis depends on
+# whether a current PMC stamp exists).  Round-4 driver line: headline 0.773, NEAREST 0.74, BICUBIC 0.707, AREA 0.762, c4 702 k (vpp_point_kernel; round 5:
+# vpp_point_rn_kernel out of a 256-frame table 776 k), c5 376 k.
+FLOORS = {"headline": 0.71, "NEAREST": 0.68, "BICUBIC": 0.65, "AREA": 0.70, "c4_fps": 690e3, "c5_fps": 340e3, "c3_fps": 2.9e6, "c2": 0.66}
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -45,13 +51,15 @@ def _check(p):
     knobs = any(k.startswith("TSVPP_") for k in os.environ)                  # (knob runs, tools/knob_matrix.sh, dispatch other -- slower -- kernels)
     if not knobs:
         assert rf["kernel"].startswith("tsvpp::vpp_bilinear_kernel")
-    assert (0.0 if knobs else 0.2) < rf["frac"] < 1.0
+    # Perf floors ("0.2 < frac" let a threshold slip that halves the headline pass): ~92 % of what the driver measured in round 4 /
+    # this round's same-box runs (boxes differ by +-4 %); knob runs dispatch other, slower kernels on purpose and only have to produce the line
+    assert (0.0 if knobs else FLOORS["headline"]) < rf["frac"] < 1.0, rf
     for wl in ("c4", "c5"):  # north_star: 1080p AND 4K at 1/2/4/8 GPUs
         o = res["config"]["other_workloads"][wl]
-        assert "error" not in o and o["frames_per_s"] > 0 and o["hbm_frac"] > (0.0 if knobs else 0.2), o
+        assert "error" not in o and o["frames_per_s"] > (0.0 if knobs else FLOORS[wl + "_fps"]), o
     for rt in ("NEAREST", "BICUBIC", "AREA"):
         o = res["config"]["other_resize_types"][rt]
-        assert "error" not in o and o["frames_per_s"] > 0, o
+        assert "error" not in o and o["frames_per_s"] > 0 and o["hbm_frac"] > (0.0 if knobs else FLOORS[rt]), o
     t = res["timing"]
     assert t["total_timed_steps"] == t["repeats"] * res["steps"] and t["mean_ms_per_step"] > 0
     return res
@@ -71,6 +79,23 @@ def test_force_dist_world1_nccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
                        env=_env(TSVPP_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=600)
     _check(p)
+
+
+@pytest.mark.skipif(any(k.startswith("TSVPP_") for k in os.environ), reason="knob runs dispatch other kernels on purpose")
+@pytest.mark.parametrize("wl,key", [("c3", "c3_fps"), ("c2", "c2")])
+def test_perf_floors_of_the_other_baseline_configurations(wl, key):
+    """C3 (512-frame launches out of a persistent frame table on the row-segment kernel: 3.25 M frames/s, 0.72 of the roofline on moved bytes; the byte-gather
+    kernel of rounds 1-4 ran 2.6 M) and C2; the headline, its three other resize types, C4 and C5 are checked on the default line above."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-others"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert res["config"]["parity"].startswith("bit-exact")
+    if wl == "c3":
+        assert res["roofline"]["kernel"] == "tsvpp::vpp_bilinear_rows_kernel<OUT,wx0>" and res["config"]["frame_table"] and res["config"]["frames_per_launch"] == 512
+        assert res["value"] > FLOORS[key], res["value"]
+    else:
+        assert res["roofline"]["kernel"] == "tsvpp::vpp_color_kernel<OUT>" and res["roofline"]["frac"] > FLOORS[key], res["roofline"]
 
 
 def test_single_frame_latency_tool():

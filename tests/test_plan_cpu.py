@@ -218,3 +218,26 @@ def test_area_weight_rows_have_unit_interior_taps():
         assert (tab[:, 1: max(1, 4 * nkx - 4)] == 1.0).all(), (num, den)        # what the kernel relies on
         assert (tab[:, 1: taps.value - 2] == 1.0).all()                        # what the table actually guarantees: taps 1 .. taps - 3
         assert (tab >= 0).all() and (tab[:, 0] > 0).all()
+
+
+def test_the_five_baseline_requests_select_the_kernels_the_profiles_name():
+    """the selection of the BASELINE configurations is pinned against what was PROFILED -- profiles/traffic_latest.json names the kernel each
+    PMC entry was taken on (tools/traffic_json.py), bench.py refuses an entry whose kernel is no longer dispatched; here the plan itself must agree, so a threshold
+    that slips in vpp_select.hip fails the CPU suite, not a later round's bench line."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    want = {"headline": "vpp_bilinear_kernel<bilinear,OUT>", "c2": "vpp_color_kernel<OUT>", "c3": "vpp_bilinear_rows_kernel<OUT,wx0>",
+            "c4": "vpp_point_rn_kernel<OUT,3:1,centre>", "c5": "vpp_area_box_kernel<6,1,OUT>"}
+    got = {}
+    for name, (sw, sh, pitch, crop, dst, rt, fcc, planes, norm) in bench.WORKLOADS.items():
+        p = plan((sw, sh), dst, bench.RESIZE[rt], fourcc=bench.FOURCC[fcc], planes=bench.PLANES[planes], norm=norm, crop=crop, pitch=pitch)
+        got[name] = p["kernel"]
+    assert got == want, got
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
+    for name, entry in traffic.items():
+        if name in want and entry.get("kernel"):
+            assert entry["kernel"].split("::")[-1] == want[name], (name, entry["kernel"], entry.get("round"))
