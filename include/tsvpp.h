@@ -156,6 +156,14 @@ int tsvpp_convert_table(tsvpp_ctx *ctx, const tsvpp_table *table, int first, int
 int tsvpp_prepare(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height);
 int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int in_height, int n_frames, void *stream);
 
+/* Memory a context keeps although it no longer uses it.  Nothing is ever freed under running work: a geometry-table set pushed out of the cache (the 1024 most recently
+ * used geometries stay) and an outgrown NV12 scratch buffer are RETIRED -- a launch already enqueued, or a captured hipGraph, may still hold their addresses, and a
+ * hipFree would synchronise the device.  A context retires at most 256 MiB of table sets (a table set is tens of KiB: several thousand distinct geometries); past that,
+ * new geometries run the kernels that compute their own coordinates (same bits, slower) and the library says so once on stderr.  tsvpp_trim releases the retired
+ * memory: call it at a QUIESCENT point -- every conversion enqueued through this context has finished and no hipGraph captured from it will be replayed again.
+ * `released_bytes` (may be NULL) receives the bytes of table sets released. */
+int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes);
+
 /* roctx ranges around every conversion ("tsvpp_convert n=.. WxH->WxH ..."), the counterpart of the reference's NVTX
  * ranges (include/Common.h:72-105 PUSH_RANGE/POP_RANGE, src/VideoProcessor.cpp:95; switched on by
  * Logger::enableNVTX / TensorStreamConverter.enable_nvtx()).  The tracer library (rocprofiler-sdk-roctx or

@@ -358,6 +358,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS")) ctx->bilinear_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_POINT_RN")) ctx->point_rn = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e); // LDS budget of the staged kernels in KiB (tests: a budget nothing fits)
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS_WAVES")) ctx->bilinear_rows_waves = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_ROWS")) ctx->bicubic_rows = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_AREA_STREAM")) ctx->area_stream = std::atoi(e);
@@ -1057,6 +1058,21 @@ int tsvpp_convert_table(tsvpp_ctx *ctx, const tsvpp_table *table, int first, int
 int tsvpp_convert(tsvpp_ctx *ctx, const tsvpp_nv12 *in, const tsvpp_params *p, void *out, void *stream) {
     void *outs[1] = { out };
     return tsvpp_convert_batch(ctx, 1, in, p, outs, stream);
+}
+
+int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes) {
+    if (released_bytes) *released_bytes = 0;
+    if (!ctx) return TSVPP_ERROR;
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
+    size_t n = geo_cache_trim(ctx->geo);
+    {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        for (uint8_t *b : ctx->retired) (void)hipFree(b); // outgrown NV12 scratch buffers of the two-pass formats (their sizes are not tracked: not counted)
+        ctx->retired.clear();
+    }
+    if (released_bytes) *released_bytes = n;
+    return TSVPP_OK;
 }
 
 int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out) {

@@ -625,6 +625,17 @@ void geo_cache_destroy(GeoCache *c) {
     delete c;
 }
 
+size_t geo_cache_trim(GeoCache *c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (uint8_t *p : c->retired) (void)hipFree(p);
+    const size_t n = c->retired_bytes;
+    c->retired.clear();
+    c->retired_bytes = 0;
+    c->warned = false;
+    return n;
+}
+
 // The tables of this launch (d: shape and LDS layout already chosen), built and uploaded on first use.  Never allocates while
 // the stream is being captured into a graph (the launch then keeps vpp_bilinear_kernel; tsvpp_prepare_batch avoids that).
 static bool geo_lookup(GeoCache *cache, bool areaup, const LaunchDesc &d, hipStream_t stream, bool may_build, LaunchDesc &out) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <map>
@@ -156,6 +157,7 @@ struct LaunchDesc {
     // down-scale taps the SAME two samples per axis as BILINEAR -- only the integer weights and the final division differ.
     // 0 = off; 1 = 3 : 2 (weights (2,1) / (1,2) by index parity, sum / 9); 2 = 2 : 1 ((1,1), sum / 4).  The divisor travels as area_rcp.
     int tap22;
+    int tap22_off;     // launch_fused's second attempt: the 2x2-tap integer tile could not be staged, the request runs as the AREA down-scale it is
     int last_col0;     // dst_w = 4 k + 2: first column of the launch's LAST tile column, shifted left so that it ends at the frame's right edge (tile_col0, vpp_device.h); 0 = no shift
     int copy16;        // no resize, Y800 / NV12 uint8 outputs: the planes are copied 16 bytes per lane (vpp_copy16_kernel), chosen by launch_fused
     // BILINEAR at sparse ratios, one wave per 64-column tile, the TAPPED rows staged as LDS-DMA row segments (vpp_bilinear_rows.hip): allowed (TSVPP_BILINEAR_ROWS: 1 = where the
@@ -189,6 +191,7 @@ struct GeoCache {
     // another thread captures in global mode invalidates that capture -- so nothing is ever freed under a live context.
     std::vector<uint8_t *> retired;
     size_t retired_bytes = 0;
+    bool warned = false;
 };
 constexpr size_t kGeoMaxEntries = 1024;
 constexpr size_t kGeoMaxRetiredBytes = (size_t)256 << 20;
@@ -198,7 +201,16 @@ constexpr size_t kGeoMaxRetiredBytes = (size_t)256 << 20;
 // that bound after several thousand distinct geometries.
 inline bool geo_cache_make_room(GeoCache *c) {
     if (c->map.size() < kGeoMaxEntries) return true;
-    if (c->retired_bytes >= kGeoMaxRetiredBytes) return false;
+    if (c->retired_bytes >= kGeoMaxRetiredBytes) {
+        //  from here on every NEW geometry runs the kernels that compute their own coordinates (same bits, 5-20 % slower for the uint8 2x2-tap and the
+        // non-dyadic BICUBIC requests) until tsvpp_trim() / tsvpp_destroy() releases the retired sets: say so, once per context
+        if (!c->warned) {
+            c->warned = true;
+            fprintf(stderr, "tsvpp: this context has retired %zu MiB of geometry tables (limit %zu MiB): new geometries get no tables until tsvpp_trim() is called at a quiescent point\n",
+                    c->retired_bytes >> 20, kGeoMaxRetiredBytes >> 20);
+        }
+        return false;
+    }
     auto victim = c->map.begin();
     for (auto it = c->map.begin(); it != c->map.end(); ++it)
         if (it->second.stamp < victim->second.stamp) victim = it;
@@ -210,6 +222,7 @@ inline bool geo_cache_make_room(GeoCache *c) {
     return true;
 }
 GeoCache *geo_cache_create();
+size_t geo_cache_trim(GeoCache *c);  // hipFree()s the RETIRED sets (tsvpp_trim: the caller guarantees that nothing in flight or captured still uses them); bytes released
 void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has selected the device
 
 // Output flavour: element type x layout.

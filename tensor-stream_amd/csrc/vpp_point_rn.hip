@@ -117,6 +117,38 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_point_rn_kernel(const LaunchD
     r32_store_tile<OUT>(d, out, ylo, yhi, clo, chi, i0, j0, run_m, run_a);
 }
 
+// ---- the same idea at the exact ratio 1 : 2 (540p -> 1080p, 1080p -> 4K): NEAREST (source sample (int)(0.5 j) = j / 2) and the AREA up-scale, whose weights are ALL zero at
+// this ratio -- src/Resize.cu:221-234: x = floor(0.5 j), xFloat = (j + 1) - (x + 1) / 0.5 is -1 for even j and 0 for odd j, both "<= 0 -> 0" -- so that its bilinear blend
+// returns tap A itself: both are 2 x 2 pixel REPLICATION, on the chroma grid alike.  Seven eighths of such a launch's bytes are output and the LDS kernels' 4 x 2-pixel
+// thread tiles spent the launch in their colour / pack / store phase (uint8 outputs 0.31-0.34 of the roofline, profiles/r04_upscale_u8_probe.txt).  Here a thread's
+// 8 x 4 output pixels are ONE luma dword of two source rows and ONE chroma dword, each byte (pair) doubled by a v_perm_b32 with a constant selector.
+template <int OUT>
+__global__ __launch_bounds__(MAX_THREADS) void vpp_rep2_kernel(const LaunchDesc d, const FrameTable t) {
+    const TileId id = decode_tile(d); // tiles of (8 tx) x (4 ty) output pixels
+    if (!id.valid) return;
+    const int lx = threadIdx.x & (d.tx - 1), ly = threadIdx.x >> d.tx_shift;
+    const int q = id.tx * d.tx + lx, n4 = id.ty * d.ty + ly;
+    const int j0 = PRN_COLS * q, i0 = PRN_ROWS * n4;
+    if (j0 >= d.dst_w || i0 >= d.dst_h) return;
+    uint8_t *out = (uint8_t *)t.out[id.frame];
+    // output rows 4 n .. 4 n + 3 <- source rows 2 n, 2 n + 1; columns 8 q .. 8 q + 7 <- source bytes 4 q .. 4 q + 3; chroma output rows 2 n, 2 n + 1 <- chroma row n,
+    // pairs 4 q .. 4 q + 3 <- source pairs 2 q, 2 q + 1 = bytes 4 q .. 4 q + 3
+    const uint8_t *py = t.y[id.frame] + (size_t)(2 * n4) * (size_t)d.pitch_y + (size_t)(4 * q);
+    const uint32_t y0 = *(const uint32_t *)py, y1 = *(const uint32_t *)(py + d.pitch_y);
+    uint32_t c = 0x80808080u;
+    if constexpr (!kLumaOnly<OUT>) c = *(const uint32_t *)(t.uv[id.frame] + (size_t)n4 * (size_t)d.pitch_uv + (size_t)(4 * q));
+    uint32_t ylo[4], yhi[4], clo[2], chi[2];
+    ylo[0] = ylo[1] = __builtin_amdgcn_perm(0u, y0, 0x01010000u); // s0 s0 s1 s1
+    yhi[0] = yhi[1] = __builtin_amdgcn_perm(0u, y0, 0x03030202u); // s2 s2 s3 s3
+    ylo[2] = ylo[3] = __builtin_amdgcn_perm(0u, y1, 0x01010000u);
+    yhi[2] = yhi[3] = __builtin_amdgcn_perm(0u, y1, 0x03030202u);
+    clo[0] = clo[1] = __builtin_amdgcn_perm(0u, c, 0x01000100u);   // U0 V0 U0 V0
+    chi[0] = chi[1] = __builtin_amdgcn_perm(0u, c, 0x03020302u);   // U1 V1 U1 V1
+    const int run_len = min(d.tx, 64), run_m = (int)threadIdx.x & (run_len - 1);
+    const int run_a = min(run_len, (d.dst_w - (j0 - PRN_COLS * run_m)) / PRN_COLS);
+    r32_store_tile<OUT>(d, out, ylo, yhi, clo, chi, i0, j0, run_m, run_a);
+}
+
 template <int N, int OFF>
 static hipError_t launch_prn(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
@@ -129,10 +161,26 @@ static hipError_t launch_prn(OutKind out, const LaunchDesc &d, const FrameTable 
     return hipGetLastError();
 }
 
-// d.r32 = 100 + 10 N + OFF (launch_fused)
+// d.r32 = 100 + 10 N + OFF, or 20: replication at 1 : 2 (launch_fused)
 hipError_t launch_point_rn(OutKind out, const LaunchDesc &d, const FrameTable &t, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     const char *name = nullptr;
+    if (d.r32 == 20) { // pixel replication at 1 : 2 (NEAREST, AREA up-scale)
+        if (info) {
+            info->kernel = "vpp_rep2_kernel<OUT>";
+            info->grid = (int)grid.x;
+            info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : (out == O_F32_MERGED || out == O_HSV_F32) ? MAX_THREADS * 96 : 16;
+            return hipSuccess;
+        }
+        switch (out) {
+#define TSVPP_REP2(O) case O: hipLaunchKernelGGL((vpp_rep2_kernel<O>), grid, block, 0, stream, d, t); break;
+            TSVPP_REP2(O_U8_PLANAR) TSVPP_REP2(O_U8_MERGED) TSVPP_REP2(O_NV12_U8) TSVPP_REP2(O_Y800_U8)
+            TSVPP_REP2(O_F32_PLANAR) TSVPP_REP2(O_F32_MERGED) TSVPP_REP2(O_NV12_F32) TSVPP_REP2(O_Y800_F32) TSVPP_REP2(O_HSV_F32)
+#undef TSVPP_REP2
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (d.r32) {
     case 130: name = "vpp_point_rn_kernel<OUT,3:1,nearest>"; break;
     case 131: name = "vpp_point_rn_kernel<OUT,3:1,centre>"; break;

@@ -44,6 +44,8 @@ static const StreamRow kStreamRows[] = {
     { M_BICUBIC, 3, 7, "profiles/r04_bicubic_r32_ab.txt: 1080p -> 720p fp32 planar 0.670 -> 0.711, uint8 merged 0.362 -> 0.548, fp32 merged 0.573 -> 0.702" },
     { M_BICUBIC, 4, 8, "profiles/r04_bicubic_r32_ab.txt: 4K -> 1080p fp32 planar 0.652 -> 0.730, uint8 merged 0.368 -> 0.631; 1080p -> 540p 0.619 -> 0.691" },
     { M_BILINEAR, 1, 10, "profiles/r04_up2_ab.txt (vpp_bilinear_up2.hip): uint8 outputs of the 1 : 2 up-scale, 0.34 on the LDS kernel (r04_upscale_u8_probe.txt)" },
+    { M_NEAREST, 1, 20, "profiles/r05_rep2_ab.txt (vpp_point_rn.hip, vpp_rep2_kernel): NEAREST at 1 : 2 is 2 x 2 pixel replication" },
+    { M_AREA_UP, 1, 20, "profiles/r05_rep2_ab.txt: the AREA up-scale at 1 : 2 has all-zero weights: the same replication" },
 };
 // The streaming kernel instance of this request, or 0.  `mode` is the mode the launch runs as (an AREA request that took the 2x2-tap integer tile,
 // LaunchDesc::tap22, arrives here as BILINEAR and is not eligible: fp32 RGB).
@@ -77,7 +79,7 @@ static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d, 
     // (profiles/r04_r32_f32_ab.txt: AREA 1080p -> 720p 0.681 vs 0.683, 4K -> 1080p 0.65 vs 0.72, BILINEAR 0.69 vs 0.77) and win for HSV, whose three
     // divisions per pixel make the launch VALU-bound (AREA 0.56 -> 0.65, BILINEAR 0.59 -> 0.67): HSV takes them, the rest only under TSVPP_R32=2
     if (!d.r32_pref) return 0;
-    if (r32 == 10) // the 1 : 2 up-scale: uint8 RGB / BGR / NV12 / Y800 (fp32 outputs are output-bound on the LDS kernel already: 0.81; TSVPP_R32=2 takes them too)
+    if (r32 == 10 || r32 == 20) // the 1 : 2 up-scales: uint8 RGB / BGR / NV12 / Y800 (fp32 outputs are output-bound on the LDS kernel already: 0.81; TSVPP_R32=2 takes them too)
         return (out < O_COUNT && (u8_flavour || (f32_out && d.r32_pref == 2))) ? r32 : 0;
     if (!(u8_flavour || (f32_out && out < O_COUNT && (out == O_HSV_F32 || d.r32_pref == 2)))) return 0;
     if (mode == M_AREA_DOWN) { // the weight pattern the kernel instance has compiled in
@@ -99,7 +101,7 @@ static void stream_shape(int r32, OutKind out, const LaunchDesc &d, int &tx, int
         if (f32_out) ty = out == O_HSV_F32 ? 4 : 2;
         return;
     }
-    if (r32 == 10) return; // the 1 : 2 up-scale: 64 x 4 threads (neighbour dwords by wave shuffle; not swept yet)
+    if (r32 == 10 || r32 == 20) return; // the 1 : 2 up-scales: 64 x 4 threads (neighbour dwords by wave shuffle; not swept yet)
     if (r32 < 7) {
         if (f32_out) ty = out == O_HSV_F32 ? 4 : 2; // fp32 outputs want short tiles (as the BICUBIC kernel below)
         // YUV444, the one VALU-bound flavour of the 2x2-tap kinds (125-137 VGPRs): lanes past the right edge cost what they idle -- 1280 columns = 2.5
@@ -146,7 +148,7 @@ static void sel_tap22(Mode &mode, OutKind out, bool vec, LaunchDesc &d) {
         const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32);
         const bool r32x = 2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h, r21 = d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h;
         // (4 k + 2 columns: the tail launch samples by MODE)
-        if (f32 && vec && !d.force_gather && d.bil_int_pref == 1 && d.r32_pref != 2 && (r32x || r21) && (d.dst_w & 3) == 0 && mode == M_AREA_DOWN && d.qx && d.qy &&
+        if (!d.tap22_off && f32 && vec && !d.force_gather && d.bil_int_pref == 1 && d.r32_pref != 2 && (r32x || r21) && (d.dst_w & 3) == 0 && mode == M_AREA_DOWN && d.qx && d.qy &&
             d.rx == 2 && d.ry == 2 && d.area_rcp != 0.0f && ((r32x && d.nx == 2 && d.ny == 2) || (r21 && d.nx == 1 && d.ny == 1)))
             d.tap22 = r32x ? 1 : 2;
         if (d.tap22) {
@@ -550,6 +552,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.rpt = 1;
     d.bicubic_int = 0;
     FusedSel S;
+    const Mode mode_in = mode;
     sel_tap22(mode, out, vec, d);
     sel_two_tap_forms(mode, d);
     d.luma_only = (out == O_Y800_U8 || out == O_Y800_F32) ? 1 : 0;
@@ -581,6 +584,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
     sel_bilinear_rows(mode, vec, sparse_gather, stream_r32, d, S);
     sel_staged(mode, vec, bicubic_staged, sparse_gather, d, S);
+    if (d.tap22 && !staged) {
+        //  sel_tap22 turned this AREA request into the 2x2-tap kernel's integer tile BEFORE its staging was known to fit; a request that does not fit
+        // (not reachable with the default 40 KiB budget at 3 : 2 / 2 : 1, but a smaller TSVPP_LDS_KB gets there) would fall through to the gather kernel with
+        // BILINEAR's weights.  Start over as the AREA down-scale it is.
+        LaunchDesc again = din;
+        again.tap22_off = 1;
+        return launch_fused(mode_in, out, vec, again, t, stream, info);
+    }
     if (!staged) d.dma = 0;
     sel_bicubic_cols(mode, vec, bc_r32, d, S, stream, info);
     const size_t bc_lds = lds_bytes;

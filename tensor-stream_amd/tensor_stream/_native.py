@@ -36,7 +36,7 @@ class Coeffs(ctypes.Structure):
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
            "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs",
            "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version",
-           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table"]
+           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table", "tsvpp_trim"]
 
 _lib = None
 
@@ -68,6 +68,8 @@ def lib():
     L.tsvpp_table_destroy.restype = None
     L.tsvpp_table_set.argtypes = [vp, i32, i32, pn, ctypes.POINTER(vp), vp]
     L.tsvpp_convert_table.argtypes = [vp, vp, i32, i32, pp, vp]
+    L.tsvpp_trim.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    L.tsvpp_trim.restype = i32
     L.tsvpp_prepare.argtypes = [vp, pp, i32, i32]
     L.tsvpp_prepare_batch.argtypes = [vp, pp, i32, i32, i32, vp]
     L.tsvpp_enable_markers.argtypes = [vp, i32]

@@ -167,6 +167,7 @@ class _Coalescer:
         self.requests = 0
 
     def convert(self, key, frame, name, fp):
+        """The caller's own result: convert_group's return value indexed by the caller's slot (a batch tensor, a list, or a _Converted: all subscriptable)."""
         out, slot = self.convert_slot(key, frame, name, fp)
         return out[slot]
 
@@ -181,6 +182,9 @@ class _Coalescer:
             grp.reqs.append((frame, name))
             self.requests += 1
             if leader:
+                if len(grp.reqs) >= self.max_batch:  # max_batch == 1: the leader fills its own group -- nobody else would close it
+                    grp.closed = True
+                    del self.open[key]
                 deadline = time.monotonic() + self.window
                 while not grp.closed:
                     left = deadline - time.monotonic()
@@ -213,6 +217,9 @@ class _Coalescer:
 class _Converted:
     """A group's batch tensor + the event recorded behind its launch on the leader's stream."""
     __slots__ = ("out", "event")
+
+    def __getitem__(self, slot):  # (_Coalescer.convert: the production coalescer returns this object, ADVICE r04)
+        return self.out[slot]
 
     def __init__(self, out, event):
         self.out, self.event = out, event

@@ -244,6 +244,14 @@ class VideoProcessor:
             self._tables = [t for t in self._tables if t is not h]
             table["handle"] = None
 
+    def trim(self):
+        """Releases the memory the context has retired (geometry tables pushed out of its cache, outgrown scratch buffers): tsvpp_trim.  Synchronises the device
+        first -- the C call itself leaves that to the caller."""
+        torch.cuda.synchronize(self.device)
+        n = ctypes.c_size_t(0)
+        N.check(self._lib.tsvpp_trim(self._ctx, ctypes.byref(n)))
+        return int(n.value)
+
     def _on_consumer_stream(self, name):
         raw = self.consumer_stream(name)
         ext = torch.cuda.ExternalStream(raw, device=self.device)

@@ -165,6 +165,20 @@ def test_coalescer_groups_concurrent_requests_and_returns_each_its_slice():
     for t in th:
         t.join(timeout=20)
     assert got == {i: i for i in range(203)} and sum(sizes) == 203 and max(sizes) <= 4 and co3.launches == len(sizes)
+    # max_batch = 1: the leader fills its own group and must not wait the window out, nor may a follower join it
+    sizes1 = []
+    co4 = _Coalescer(lambda frames, fp: (sizes1.append(len(frames)), list(frames))[1], window=5.0, max_batch=1)
+    t0 = time.monotonic()
+    th = [threading.Thread(target=lambda i=i: got.__setitem__(1000 + i, co4.convert("k", i, f"c{i}", None))) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=20)
+    assert time.monotonic() - t0 < 2.0 and sizes1 == [1] * 8 and all(got[1000 + i] == i for i in range(8))
+    # the production coalescer's groups return a _Converted (batch tensor + event): convert() indexes it like a list
+    from tensor_stream.tensor_stream import _Converted
+    co5 = _Coalescer(lambda frames, fp: _Converted([f * 10 for f in frames], None), window=0.01)
+    assert co5.convert("k", 7, "c", None) == 70
     # an error in the batched conversion reaches every member of the group
     co2 = _Coalescer(lambda frames, fp: (_ for _ in ()).throw(RuntimeError("boom")), window=0.02)
     out = []

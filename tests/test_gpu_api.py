@@ -189,3 +189,26 @@ def test_roctx_ranges_can_be_switched_on(vpp, oracle):
     finally:
         vpp.enable_markers(False)
     assert np.array_equal(out.cpu().numpy().ravel(), _ref(oracle, f, (160, 120), 2, RGB24, False))
+
+
+def test_trim_releases_retired_memory_and_the_context_keeps_working(oracle):
+    """tsvpp_trim (ADVICE r04): nothing is freed under running work -- geometry-table sets pushed out of the cache and outgrown scratch buffers are retired;
+    trim releases them at a quiescent point.  Here: outgrow the two-pass scratch twice, trim, convert again (same bits)."""
+    import tensor_stream as ts
+    v = ts.VideoProcessor(device=0, max_consumers=1)
+    try:
+        fp = ts.FrameParameters(width=300, height=200, resize_type=1, pixel_format=4, planes_pos=1, normalization=False)  # UYVY behind a resize: two passes
+        y, uv = synth_nv12(640, 360, seed=12)
+        ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+        ref, _, _ = oracle.convert(y, uv, dst=(300, 200), resize_type=1, fourcc=4, planes=1, normalization=False, nthreads=4, width=640)
+        for n in (1, 3, 9):  # the scratch is outgrown twice: two retired buffers
+            out = v.convert_batch([ty] * n, [tuv] * n, fp, width=640)
+        torch.cuda.synchronize()
+        assert np.array_equal(out[8].cpu().numpy().ravel(), ref)
+        assert v.trim() == 0          # (bytes of TABLE sets released: none were retired here; the scratch buffers are not counted)
+        out = v.convert_batch([ty] * 9, [tuv] * 9, fp, width=640)
+        torch.cuda.synchronize()
+        assert np.array_equal(out[0].cpu().numpy().ravel(), ref) and np.array_equal(out[8].cpu().numpy().ravel(), ref)
+        assert v.trim() == 0
+    finally:
+        v.Close()

@@ -65,3 +65,21 @@ def test_extreme_frames(vpp, oracle):
     for dst, rt in [((640, 240), AREA), ((480, 180), AREA)]:
         check(vpp, oracle, y, uv, 960, dst, rt)
         check(vpp, oracle, y, uv, 960, dst, rt, planes=1, fourcc=1)
+
+
+def test_a_tile_that_cannot_be_staged_runs_as_the_area_request_it_is(oracle, monkeypatch):
+    """sel_tap22 used to turn the AREA request into BILINEAR before its staging was known to fit; with an LDS budget nothing fits (TSVPP_LDS_KB=2, read
+    when a context is created) the launch fell through to the gather kernel -- with BILINEAR's weights.  It now starts over as AREA: same bits as the oracle."""
+    import tensor_stream as ts
+    monkeypatch.setenv("TSVPP_LDS_KB", "2")
+    v = ts.VideoProcessor(device=0, max_consumers=1)
+    try:
+        y, uv = synth_nv12(1920, 1080, seed=44, pitch=2048)
+        fp = ts.FrameParameters(width=1280, height=720, resize_type=AREA, pixel_format=2, planes_pos=0, normalization=True)
+        assert ts.describe(fp, 1920, 1080, pitch=2048)["kernel"].startswith("vpp_fused_gather_kernel")  # (describe reads the same knob)
+        got = v.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=1920)
+        torch.cuda.synchronize()
+        ref, _, _ = oracle.convert(y, uv, dst=(1280, 720), resize_type=AREA, fourcc=2, planes=0, normalization=True, nthreads=8, width=1920)
+        assert np.array_equal(got.cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8))
+    finally:
+        v.Close()
