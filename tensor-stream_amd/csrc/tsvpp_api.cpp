@@ -249,6 +249,7 @@ struct tsvpp_ctx {
     int bicubic_rows = 0;           // TSVPP_BICUBIC_ROWS: its tile height (8 / 16 / 24 / 32; 0 = automatic)
     int bicubic_dma = 1;            // TSVPP_BICUBIC_DMA: its source rows through a wave-private LDS-DMA ring (0: per-lane loads)
     int bilinear_rows = 1;          // TSVPP_BILINEAR_ROWS: BILINEAR at sparse ratios with the tapped rows as LDS-DMA row segments (vpp_bilinear_rows.hip; 1: ratio product >= 12, 2: wherever it applies, 0: byte gathers)
+    int bicubic_u8x = 1;            // TSVPP_BICUBIC_U8X: uint8 outputs of the wave-per-tile BICUBIC kernel through the 8 x 4 output side of the streaming kernels
     int point_rn = 1;               // TSVPP_POINT_RN: streaming point sampler at exact integer ratios 3 / 4 / 5 (vpp_point_rn.hip; 0: the LDS point kernel)
     int bilinear_rows_waves = 0;    // TSVPP_BILINEAR_ROWS_WAVES: its waves per workgroup (1 / 2 / 4; 0 = automatic)
     int geo_pref = 1;               // TSVPP_GEO: host-built geometry tables for the 2x2-tap kernel's window tiles (1: where measured to win, 2: wherever they apply)
@@ -357,6 +358,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_BICUBIC_INT")) ctx->bicubic_int = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BICUBIC_COLS")) ctx->bicubic_cols = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS")) ctx->bilinear_rows = std::atoi(e);
+    if (const char *e = std::getenv("TSVPP_BICUBIC_U8X")) ctx->bicubic_u8x = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_POINT_RN")) ctx->point_rn = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_LDS_KB")) ctx->lds_kb = std::atoi(e); // LDS budget of the staged kernels in KiB (tests: a budget nothing fits)
     if (const char *e = std::getenv("TSVPP_BILINEAR_ROWS_WAVES")) ctx->bilinear_rows_waves = std::atoi(e);
@@ -420,6 +422,7 @@ void fill_desc(const tsvpp_ctx *ctx, const Plan &pl, int pitch_y, int pitch_uv, 
     d.r32_pref = ctx->r32;
     d.bil_rows_pref = ctx->bilinear_rows;
     d.point_rn_pref = ctx->point_rn;
+    d.bc_u8x_pref = ctx->bicubic_u8x;
     d.br_waves = ctx->bilinear_rows_waves; // (forced; launch_fused chooses)
     d.geo_cache = ctx->geo;
 }

@@ -40,6 +40,7 @@
 // multiple of 1/16, so every C_k is exact): no tie test at all, a tie rounds up as round() does for positive values and
 // negative values clamp to 0 either way.
 #include "vpp_device.h"
+#include "vpp_r32_store.h"
 
 #include <vector>
 
@@ -414,6 +415,34 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_cols_kernel(const Lau
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    // uint8 outputs whose width is a multiple of 8 and height a multiple of 4 (host: LaunchDesc::bc_u8x): the output side of the streaming kernels (vpp_r32_store.h) --
+    // a lane takes 8 columns x 4 rows of the result tiles as packed dwords, 8-byte planar stores / merged rows exchanged into 16-byte stores, instead of 4 x 2-pixel
+    // thread tiles with 4-byte stores (round 5; 720p -> 1080p uint8: profiles/r05_bicubic_cols_u8_ab.txt)
+    if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED || OUT == O_NV12_U8 || OUT == O_Y800_U8) {
+        if (d.bc_u8x) {
+            const int gx = lane & 7, gy = lane >> 3; // 8 column groups x 8 row groups of a 64 x 32 tile
+            const int j0 = j_first + 8 * gx, r0 = 4 * gy;
+            if (j0 >= d.dst_w || r0 >= nrows) return;
+            uint32_t ylo[4], yhi[4], clo[2] = { 0x80808080u, 0x80808080u }, chi[2] = { 0x80808080u, 0x80808080u };
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t *p = (const uint32_t *)(yt + (r0 + r) * 64 + 8 * gx);
+                ylo[r] = p[0];
+                yhi[r] = p[1];
+            }
+            if constexpr (!kLumaOnly<OUT>) {
+#pragma unroll
+                for (int rc = 0; rc < 2; rc++) {
+                    const uint32_t *p = (const uint32_t *)(uvt + ((r0 >> 1) + rc) * 64 + 8 * gx);
+                    clo[rc] = p[0];
+                    chi[rc] = p[1];
+                }
+            }
+            const int run_a = min(8, (d.dst_w - j_first) >> 3);
+            r32_store_tile<OUT>(d, (uint8_t *)t.out[id.frame], ylo, yhi, clo, chi, i_first + r0, j0, gx, run_a);
+            return;
+        }
+    }
     // colour conversion + stores: 16 x 4 thread tiles of 4 x 2 pixels per 8-row slab
     const int lx = lane & 15, ly = lane >> 4;
     const int j0 = j_first + lx * PXW;

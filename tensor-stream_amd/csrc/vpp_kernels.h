@@ -143,6 +143,7 @@ struct LaunchDesc {
     // bc_dma_pref / bc_dma: source rows through a wave-private LDS-DMA ring (TSVPP_BICUBIC_DMA; horizontal ratios below 3.7) instead of
     // per-lane loads: the 16-byte chunks (lanes) a row segment takes, 0 = direct loads; bc_ring_bytes: that ring; bc_wave_bytes: LDS bytes of one wave (ring + H plane with column stride hcs_y + result tiles)
     int bicubic_cols_pref, bicubic_cols, bc_rows, bc_sparse, bc_wave_bytes, bc_dma_pref, bc_dma, bc_ring_bytes;
+    int bc_u8x_pref, bc_u8x; // uint8 outputs leave through the 8 x 4 output side of the streaming kernels (dst_w % 8 == 0, dst_h % 4 == 0; TSVPP_BICUBIC_U8X=0: the 4 x 2 thread tiles)
     // luma columns [dst_w] | chroma pair columns [dst_w / 2] as BcEntry records, then the rows in blocks of four (32 ints: ws x4 | sel x4 |
     // l0 x4 | l1 x4 | l2 x4 | bias x4 | w x4 | pad: a wave fetches four rows' parameters with scalar loads off ONE address): luma row
     // blocks, chroma row blocks; bc_npy / bc_npc = their numbers (rows / 4 rounded up, + 1)

@@ -530,6 +530,9 @@ static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, Fus
         }
         if (best_r) {
             d.bicubic_cols = exact ? 2 : 1;
+            // uint8 flavours: the 8 x 4 output side of the streaming kernels -- only where its 64 lanes have work (32-row tiles: up-scales, +2..5 %); 8- / 16-row
+            // tiles leave 48 / 32 of them idle and lose 3..5 % (profiles/r05_bicubic_cols_u8_ab.txt).  TSVPP_BICUBIC_U8X=2: every tile height, 0: never.
+            d.bc_u8x = (d.bc_u8x_pref && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0 && (best_r == 32 || d.bc_u8x_pref == 2)) ? 1 : 0;
             d.bc_sparse = sparse ? 1 : 0;
             d.bc_dma = dma ? (d.bc_dma_pref > 1 ? 16 : dma_lanes) : 0; // TSVPP_BICUBIC_DMA=2: 256-byte segments whatever the ratio (A/B)
             d.bc_ring_bytes = ring_bytes;

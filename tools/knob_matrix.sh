@@ -9,6 +9,9 @@ TSVPP_BILINEAR_ROWS=2
 TSVPP_BILINEAR_ROWS_WAVES=1
 TSVPP_POINT_RN=0
 TSVPP_POINT_RN=2
+TSVPP_BICUBIC_U8X=0
+TSVPP_BICUBIC_U8X=2
+TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_U8X=2
 TSVPP_DMA=0
 TSVPP_BILINEAR_INT=0
 TSVPP_BILINEAR_INT=2
