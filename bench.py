@@ -49,6 +49,10 @@ METRIC = "1080p NV12→720p BGR24 planar fp32 frames/sec per GPU; achieved HBM G
 WORKLOADS = {
     # name: (src_w, src_h, pitch, crop, dst, resize, fourcc, planes, norm)
     "headline": (1920, 1080, 2048, (0, 0, 0, 0), (1280, 720), "BILINEAR", "BGR24", "PLANAR", True),
+    # C1 (BASELINE.json configs[0]): the conversion the reference's CPU plumbing case names -- bunny.mp4's 1280x720 NV12 -> RGB24 MERGED uint8 at native size -- on the GPU
+    # path, with the CPU oracle beside it (cpu_baseline; swscale itself does not exist in this image).  Frames are synthetic like every bench workload; the real
+    # picture of the clip is a parity fixture (tests/test_gpu_bunny.py).
+    "c1": (1280, 720, 1280, (0, 0, 0, 0), (0, 0), "NEAREST", "RGB24", "MERGED", False),
     "c2": (1920, 1080, 2048, (0, 0, 0, 0), (0, 0), "NEAREST", "BGR24", "PLANAR", True),
     "c3": (1920, 1080, 2048, (0, 0, 1280, 720), (256, 256), "BILINEAR", "RGB24", "PLANAR", True),
     "c4": (3840, 2160, 3840, (0, 0, 0, 0), (1280, 720), "BICUBIC", "BGR24", "MERGED", False),

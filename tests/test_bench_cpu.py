@@ -25,7 +25,7 @@ def _line(out):
 
 def test_algorithmic_bytes_match_survey_8d():
     # SURVEY.md 8(d) "Per-config numbers"
-    want = {"headline": 14169600, "c2": 27993600, "c3": 2168832, "c4": 15206400, "c5": 15206400}
+    want = {"headline": 14169600, "c1": 4147200, "c2": 27993600, "c3": 2168832, "c4": 15206400, "c5": 15206400}
     for name, s in bench.WORKLOADS.items():
         assert bench.algorithmic_bytes(s[0], s[1], s[3], s[4], s[8]) == want[name], name
     assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]

@@ -220,7 +220,7 @@ def test_area_weight_rows_have_unit_interior_taps():
         assert (tab >= 0).all() and (tab[:, 0] > 0).all()
 
 
-def test_the_five_baseline_requests_select_the_kernels_the_profiles_name():
+def test_the_baseline_requests_select_the_kernels_the_profiles_name():
     """the selection of the BASELINE configurations is pinned against what was PROFILED -- profiles/traffic_latest.json names the kernel each
     PMC entry was taken on (tools/traffic_json.py), bench.py refuses an entry whose kernel is no longer dispatched; here the plan itself must agree, so a threshold
     that slips in vpp_select.hip fails the CPU suite, not a later round's bench line."""
@@ -230,7 +230,7 @@ def test_the_five_baseline_requests_select_the_kernels_the_profiles_name():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    want = {"headline": "vpp_bilinear_kernel<bilinear,OUT>", "c2": "vpp_color_kernel<OUT>", "c3": "vpp_bilinear_rows_kernel<OUT,wx0>",
+    want = {"headline": "vpp_bilinear_kernel<bilinear,OUT>", "c1": "vpp_color_kernel<OUT>", "c2": "vpp_color_kernel<OUT>", "c3": "vpp_bilinear_rows_kernel<OUT,wx0>",
             "c4": "vpp_point_rn_kernel<OUT,3:1,centre>", "c5": "vpp_area_box_kernel<6,1,OUT>"}
     got = {}
     for name, (sw, sh, pitch, crop, dst, rt, fcc, planes, norm) in bench.WORKLOADS.items():
