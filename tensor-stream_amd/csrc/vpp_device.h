@@ -436,6 +436,18 @@ __device__ __forceinline__ void st4o(uint8_t *base, uint32_t off, float a, float
     else if (nt == 1) __builtin_nontemporal_store(v, (vf4 *)(base + off));
     else *(vf4 *)(base + off) = v;
 }
+// 8- and 16-byte stores of packed uint8 rows with the non-temporal hint, as inline asm: written as `if (nt) __builtin_nontemporal_store(..) else plain store` the two
+// branches hold the same store and the compiler merges them into ONE PLAIN store -- the hint was silently dropped from every uint8 flavour of the streaming kernels
+// until round 5 (found with a -D build that had no else branch: merged uint8 outputs +5..27 %, profiles/r05_prn_nt_variants.txt).  `base` is wave-uniform.
+typedef uint32_t nt_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st8_nt(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi) {
+    const nt_u32x2 v = { lo, hi };
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st16_nt(uint8_t *base, uint32_t off, nt_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
 // 4-byte uint8 stores are always plain: `sc1` turned each into its own fabric write (-36 %), non-temporal bought nothing
 __device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int) { *(uint32_t *)(base + off) = v; }
 // Four integer-valued floats -> packed bytes with v_cvt_pk_u8_f32 (one instruction per byte; it saturates to
@@ -637,7 +649,9 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                         typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 v = *(const u32x4 *)(run.lds + 16 * run.m);
-                        *(u32x4a4 *)(o + (3u * (pix - 4u * (uint32_t)run.m) + 16u * (uint32_t)run.m)) = v; // rows start on 4-byte boundaries only
+                        const uint32_t off16 = 3u * (pix - 4u * (uint32_t)run.m) + 16u * (uint32_t)run.m; // rows start on 4-byte boundaries only
+                        if (nt) st16_nt(o, off16, (nt_u32x4){ v.x, v.y, v.z, v.w }); // (round 5: the exchanged 16-byte stores cover whole lines like the fp32 ones)
+                        else *(u32x4a4 *)(o + off16) = v;
                     }
                     __builtin_amdgcn_wave_barrier();
                 } else {

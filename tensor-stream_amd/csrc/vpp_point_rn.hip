@@ -24,7 +24,7 @@ template <int ND> __device__ __forceinline__ void prn_load(const uint8_t *p, uin
     static_assert(ND % 2 == 0, "runs are 8 N bytes");
 #pragma unroll
     for (int k = 0; k + 4 <= ND; k += 4) {
-        const prn_x4 v = *(const prn_x4 *)(p + 4 * k);
+        const prn_x4 v = *(const prn_x4 *)(p + 4 * k); // (plain: non-temporal loads measured -1..-14 %, profiles/r05_prn_nt_variants.txt)
         dw[k] = v.x; dw[k + 1] = v.y; dw[k + 2] = v.z; dw[k + 3] = v.w;
     }
     if constexpr (ND % 4 == 2) {

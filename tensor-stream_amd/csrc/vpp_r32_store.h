@@ -18,8 +18,12 @@ typedef uint32_t bq4 __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ void bc_st8(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int nt) {
     const bq2 v = { lo, hi };
-    if (nt) __builtin_nontemporal_store(v, (bq2 *)(base + off));
+    if (nt) st8_nt(base, off, lo, hi); // (inline asm: see st8_nt, vpp_device.h -- the builtin's hint did not survive)
     else *(bq2 *)(base + off) = v;
+}
+__device__ __forceinline__ void bc_st16(uint8_t *base, uint32_t off, bq4 v, int nt) {
+    if (nt) st16_nt(base, off, (nt_u32x4){ v.x, v.y, v.z, v.w });
+    else *(bq4 *)(base + off) = v;
 }
 // the four bytes of a dword as integer-valued floats (v_cvt_f32_ubyte0..3)
 __device__ __forceinline__ void bc_unpack4(uint32_t w, float *f) {
@@ -181,10 +185,12 @@ __device__ __forceinline__ void r32_store_tile(const LaunchDesc &d, uint8_t *out
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t row0 = 3u * (pix - (uint32_t)(BCR_COLS * run_m)); // first byte of the run in this row
                         const bq4 v0 = *(const bq4 *)(run_lds + 16 * run_m);
-                        *(bq4 *)(out + row0 + 16u * (uint32_t)run_m) = v0;
+                        // (round 5) non-temporal like every other whole-line store of the library: the exchanged 16-byte stores were plain until then, and that alone
+                        // cost the uint8 merged flavours of the streaming kernels 5..27 % (profiles/r05_prn_nt_variants.txt, r05_u8_merged_nt_ab.txt)
+                        bc_st16(out, row0 + 16u * (uint32_t)run_m, v0, nt);
                         if (2 * run_m < run_a) {
                             const bq4 v1 = *(const bq4 *)(run_lds + 16 * (run_a + run_m));
-                            *(bq4 *)(out + row0 + 16u * (uint32_t)(run_a + run_m)) = v1;
+                            bc_st16(out, row0 + 16u * (uint32_t)(run_a + run_m), v1, nt);
                         }
                         __builtin_amdgcn_wave_barrier();
                     } else {
