@@ -172,7 +172,7 @@ template <int P2> __device__ __forceinline__ void r32_load(const uint8_t *p, uin
 }
 __device__ __forceinline__ void st8(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int nt) {
     const r32x2 v = { lo, hi };
-    if (nt) st8_nt(base, off, lo, hi); // (inline asm: see st8_nt, vpp_device.h -- the builtin's hint did not survive)
+    if (nt) st8_nt(base, off, lo, hi, nt); // (inline asm: see st8_nt, vpp_device.h -- the builtin's hint did not survive)
     else *(r32x2 *)(base + off) = v;
 }
 
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
                               pack_u8x4(c[6], yf[6], c[7], yf[7]) };
             const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
             // 16 bytes per lane, 1 KiB contiguous per wave
-            if (nt) st16_nt(out, 2u * pix, (nt_u32x4){ v.x, v.y, v.z, v.w }); // (inline asm: see st8_nt, vpp_device.h)
+            if (nt) st16_nt(out, 2u * pix, (nt_u32x4){ v.x, v.y, v.z, v.w }, nt); // (inline asm: see st8_nt, vpp_device.h)
             else *(r32x4 *)(out + 2u * (size_t)pix) = v;
         }
         return;
@@ -432,11 +432,11 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t row0 = 3u * (pix - (uint32_t)(R32_COLS * run_m)); // first byte of the run in this row
                         const r32x4 v0 = *(const r32x4 *)(run_lds + 16 * run_m);
-                        if (nt) st16_nt(out, row0 + 16u * (uint32_t)run_m, (nt_u32x4){ v0.x, v0.y, v0.z, v0.w }); // (round 5: see vpp_r32_store.h)
+                        if (nt) st16_nt(out, row0 + 16u * (uint32_t)run_m, (nt_u32x4){ v0.x, v0.y, v0.z, v0.w }, nt); // (round 5: see vpp_r32_store.h)
                         else *(r32x4 *)(out + row0 + 16u * (uint32_t)run_m) = v0;
                         if (2 * run_m < run_a) {
                             const r32x4 v1 = *(const r32x4 *)(run_lds + 16 * (run_a + run_m));
-                            if (nt) st16_nt(out, row0 + 16u * (uint32_t)(run_a + run_m), (nt_u32x4){ v1.x, v1.y, v1.z, v1.w });
+                            if (nt) st16_nt(out, row0 + 16u * (uint32_t)(run_a + run_m), (nt_u32x4){ v1.x, v1.y, v1.z, v1.w }, nt);
                             else *(r32x4 *)(out + row0 + 16u * (uint32_t)(run_a + run_m)) = v1;
                         }
                         __builtin_amdgcn_wave_barrier();

@@ -441,15 +441,23 @@ __device__ __forceinline__ void st4o(uint8_t *base, uint32_t off, float a, float
 // until round 5 (found with a -D build that had no else branch: merged uint8 outputs +5..27 %, profiles/r05_prn_nt_variants.txt).  `base` is wave-uniform.
 typedef uint32_t nt_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st8_nt(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi) {
+// (`pol`: the launch's store policy, non-zero here -- 2 = `sc1`, anything else non-temporal)
+__device__ __forceinline__ void st8_nt(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int pol = 1) {
     const nt_u32x2 v = { lo, hi };
-    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+    if (pol == 2) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
-__device__ __forceinline__ void st16_nt(uint8_t *base, uint32_t off, nt_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+__device__ __forceinline__ void st16_nt(uint8_t *base, uint32_t off, nt_u32x4 v, int pol = 1) {
+    if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 // 4-byte uint8 stores are always plain: `sc1` turned each into its own fabric write (-36 %), non-temporal bought nothing
-__device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int) { *(uint32_t *)(base + off) = v; }
+// (re-measured in round 5 with the hint as inline asm, profiles/r05_st1_nt_variants.txt: the colour-only kernel's uint8 planar output +4 % (0.738 -> 0.766), AREA 1080p ->
+// 960x544 +3 %, every other kernel -1..-5 %: bit 2 of the store policy, set by launch_fused for the colour-only kernel alone)
+__device__ __forceinline__ void st1o(uint8_t *base, uint32_t off, uint32_t v, int nt) {
+    if (nt & 4) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *(uint32_t *)(base + off) = v;
+}
 // Four integer-valued floats -> packed bytes with v_cvt_pk_u8_f32 (one instruction per byte; it saturates to
 // [0, 255], so the uint8 paths need no separate clamp after the truncation; it rounds to nearest, so the
 // truncation itself stays -- measured: without v_trunc the parity tests fail)
@@ -650,7 +658,7 @@ __device__ __forceinline__ void color_store_row(const float Yf[PXW], const float
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 v = *(const u32x4 *)(run.lds + 16 * run.m);
                         const uint32_t off16 = 3u * (pix - 4u * (uint32_t)run.m) + 16u * (uint32_t)run.m; // rows start on 4-byte boundaries only
-                        if (nt) st16_nt(o, off16, (nt_u32x4){ v.x, v.y, v.z, v.w }); // (round 5: the exchanged 16-byte stores cover whole lines like the fp32 ones)
+                        if (nt) st16_nt(o, off16, (nt_u32x4){ v.x, v.y, v.z, v.w }, nt); // (round 5: the exchanged 16-byte stores cover whole lines like the fp32 ones)
                         else *(u32x4a4 *)(o + off16) = v;
                     }
                     __builtin_amdgcn_wave_barrier();

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_copy16_kernel(const LaunchDes
     const uint32_t plane = (uint32_t)d.dst_w * (uint32_t)d.dst_h;
     auto st = [&](uint32_t off, const cp_x4 &v) {
         const cp_x4a a = { v.x, v.y, v.z, v.w };
-        if (d.nt_stores) st16_nt(out, off, (nt_u32x4){ v.x, v.y, v.z, v.w }); // (inline asm: see st8_nt, vpp_device.h)
+        if (d.nt_stores) st16_nt(out, off, (nt_u32x4){ v.x, v.y, v.z, v.w }, d.nt_stores); // (inline asm: see st8_nt, vpp_device.h)
         else *(cp_x4a *)(out + off) = a;
     };
 #pragma unroll

@@ -18,11 +18,11 @@ typedef uint32_t bq4 __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ void bc_st8(uint8_t *base, uint32_t off, uint32_t lo, uint32_t hi, int nt) {
     const bq2 v = { lo, hi };
-    if (nt) st8_nt(base, off, lo, hi); // (inline asm: see st8_nt, vpp_device.h -- the builtin's hint did not survive)
+    if (nt) st8_nt(base, off, lo, hi, nt); // (inline asm: see st8_nt, vpp_device.h -- the builtin's hint did not survive)
     else *(bq2 *)(base + off) = v;
 }
 __device__ __forceinline__ void bc_st16(uint8_t *base, uint32_t off, bq4 v, int nt) {
-    if (nt) st16_nt(base, off, (nt_u32x4){ v.x, v.y, v.z, v.w });
+    if (nt) st16_nt(base, off, (nt_u32x4){ v.x, v.y, v.z, v.w }, nt);
     else *(bq4 *)(base + off) = v;
 }
 // the four bytes of a dword as integer-valued floats (v_cvt_f32_ubyte0..3)

@@ -181,6 +181,8 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
         const bool f32_lines = (out == O_F32_PLANAR || out == O_NV12_F32 || out == O_Y800_F32) || (vec && (out == O_F32_MERGED || out == O_HSV_F32));
         const bool f32_partial = !vec && (out == O_F32_MERGED || out == O_HSV_F32);
         d.nt_stores = f32_partial ? 0 : ((mode == M_NONE && f32_lines) ? 2 : 1);
+        // bit 2: the 4-byte uint8 stores non-temporal too -- only the colour-only kernel's planar output gains (st1o, vpp_device.h)
+        if (mode == M_NONE && out == O_U8_PLANAR && vec) d.nt_stores = 1 | 4;
     }
 }
 
