@@ -1186,6 +1186,6 @@ const char *tsvpp_strerror(int status) {
     return "unknown status";
 }
 
-const char *tsvpp_version(void) { return "tsvpp 0.2.0 gfx950"; }
+const char *tsvpp_version(void) { return "tsvpp 0.3.0 gfx950"; }
 
 } // extern "C"
