@@ -959,7 +959,7 @@ def run(args):
             sp[5] = rname
             others[rname] = side(tuple(sp))
         other_wl = {}
-        for wl in ("c4", "c5"):
+        for wl in ("c1", "c2", "c3", "c4", "c5"):  # every BASELINE configuration rides along in the default line (C3 / C4 out of persistent frame tables: DEFAULT_BATCH)
             other_wl[wl] = side(WORKLOADS[wl], wl_name=wl)
 
     if rank == 0:
@@ -972,7 +972,8 @@ def run(args):
         res = {
             "metric": metric_name(name, args.resize),
             "value": round(frames / wall, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "warmup_steps_total": args.warmup + extra,  # `warmup` echoes W; the time-based warm-up (--warmup-ms) runs untimed steps on top of it
+            "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if norm else "u8", "data": "stub" if stub else "synthetic",
             "config": {"workload": f"{src_w}x{src_h} NV12 (pitch {pitch}) crop{list(crop)} -> {dst[0] or src_w}x{dst[1] or src_h} "
                                    f"{rt if dst[0] else 'no-resize'} -> {fcc} {planes} {'fp32 /255' if norm else 'uint8'}",

@@ -132,7 +132,9 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
  *                         freed on return, conversions enqueued on the same stream afterwards see the new entries.
  *   tsvpp_convert_table   == tsvpp_convert_batch over entries [first, first + n), same results, same status codes.
  *   tsvpp_table_destroy   frees the table (the caller has waited for conversions that use it).
- * A table belongs to the context that created it (its device). */
+ * A table belongs to the context that created it (its device).  tsvpp_table_set calls are serialised against each other; a tsvpp_convert_table that runs
+ * concurrently with a tsvpp_table_set of the SAME entries from another thread is the caller's race (as two writers of one AVFrame would be), and a captured
+ * hipGraph replays the table as the device holds it at replay time (entries are read by the kernels, not baked into the graph). */
 #define TSVPP_MAX_TABLE_LAUNCH 1024
 typedef struct tsvpp_table tsvpp_table;
 int tsvpp_table_create(tsvpp_ctx *ctx, int capacity, tsvpp_table **out_table);

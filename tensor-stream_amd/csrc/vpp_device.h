@@ -811,6 +811,17 @@ __device__ __forceinline__ TileId decode_tile(const LaunchDesc &d) {
         t.valid = row < d.tiles_y * d.n_frames;
         return t;
     }
+    if (d.tile_order >= 3) { // as 0, but an XCD takes G = 2 / 4 / 8 CONSECUTIVE tile rows (order 3 / 4 / 5): longer runs of output rows per XCD, vertical halos in one L2
+        const int sh = d.tile_order - 2, G = 1 << sh;
+        const int x = blockIdx.x % NUM_XCD, q = blockIdx.x / NUM_XCD;
+        const int group = q / (G * d.tiles_x), within = q - group * G * d.tiles_x;
+        t.tx = within >> sh;
+        const int row = G * (group * NUM_XCD + x) + (within & (G - 1));
+        t.frame = row / d.tiles_y;
+        t.ty = row - t.frame * d.tiles_y;
+        t.valid = row < d.tiles_y * d.n_frames;
+        return t;
+    }
     const int total = tiles * d.n_frames;
     const int logical = d.tile_order == 1 ? (int)blockIdx.x : (int)((blockIdx.x % NUM_XCD) * d.blocks_per_xcd + blockIdx.x / NUM_XCD);
     t.valid = logical < total;

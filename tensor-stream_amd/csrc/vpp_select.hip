@@ -642,6 +642,10 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         const long rows = (long)d.tiles_y * d.n_frames;
         d.blocks_per_xcd = (int)(((rows + NUM_XCD - 1) / NUM_XCD) * d.tiles_x);
     }
+    if (d.tile_order >= 3) { // G = 2 / 4 / 8 consecutive tile rows per XCD: rows padded to a multiple of 8 G
+        const long rows = (long)d.tiles_y * d.n_frames, G = 1L << (d.tile_order - 2);
+        d.blocks_per_xcd = (int)(((rows + G * NUM_XCD - 1) / (G * NUM_XCD)) * G * d.tiles_x);
+    }
     if (info) {
         info->tail = d.last_col0 > 0 ? 2 : 0; // (1: the tail launch below)
         info->tx = d.tx;
@@ -682,7 +686,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     td.tiles_x = 1;
     td.tiles_y = (d.dst_h + td.ty * PXH - 1) / (td.ty * PXH);
     const long rows = (long)td.tiles_y * td.n_frames;
-    td.blocks_per_xcd = (int)((rows + NUM_XCD - 1) / NUM_XCD); // tiles_x == 1: the same for every tile order
+    td.blocks_per_xcd = (int)((rows + NUM_XCD - 1) / NUM_XCD); // tiles_x == 1: the same for tile orders 0 .. 2
+    if (td.tile_order >= 3) {
+        const long G = 1L << (td.tile_order - 2);
+        td.blocks_per_xcd = (int)(((rows + G * NUM_XCD - 1) / (G * NUM_XCD)) * G);
+    }
     return dispatch(false, false, td, 0, nullptr);
 }
 

@@ -231,7 +231,7 @@ def test_gpus_8_self_spawn_on_gloo():
     assert len(pr["frames_per_s"]) == 8 and len(pr["host_issue_ms_per_step"]) == 8 and all(x > 0 for x in pr["frames_per_s"])
     assert abs(res["value"] - 8 * 64 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3
     ow = res["config"]["other_workloads"]
-    assert set(ow) == {"c4", "c5"} and all(ow[k]["frames_per_s"] > 0 for k in ow)
+    assert set(ow) == {"c1", "c2", "c3", "c4", "c5"} and all(ow[k]["frames_per_s"] > 0 for k in ow)
     assert "cpu_baseline" not in res
 
 

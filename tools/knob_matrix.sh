@@ -43,6 +43,8 @@ TSVPP_AREA_STREAM=0
 TSVPP_AREA_STREAM=2
 TSVPP_TILE_ORDER=1
 TSVPP_TILE_ORDER=2
+TSVPP_TILE_ORDER=3
+TSVPP_TILE_ORDER=5
 TSVPP_NT=0
 TSVPP_NT=2
 TSVPP_R32=0

@@ -7,10 +7,10 @@ try:
 except Exception as e:
     print('ERROR', e)"; }
 {
-echo "# uint8 outputs, store policy of the 8- / 16-byte stores: default (non-temporal) vs TSVPP_NT=2 (sc1), same box"
-for c in 3840x2160:1280x720:BICUBIC:BGR24:MERGED:0 1920x1080:1280x720:BILINEAR:RGB24:MERGED:0 1920x1080:1280x720:BILINEAR:RGB24:PLANAR:0 1920x1080:1280x720:BICUBIC:RGB24:MERGED:0 960x540:1920x1080:BILINEAR:RGB24:MERGED:0 960x540:1920x1080:AREA:RGB24:PLANAR:0 1920x1080:1920x1080:NEAREST:RGB24:MERGED:0 1920x1080:1920x1080:NEAREST:RGB24:PLANAR:0 1920x1080:1920x1080:NEAREST:Y800:MERGED:0 1920x1080:640x360:AREA:RGB24:MERGED:0 3840x2160:1920x1080:BILINEAR:RGB24:MERGED:0; do
-  for e in TSVPP_X=0 TSVPP_NT=2; do
-    printf "%-48s %-12s " "$c" "$e"; env $e python bench.py --custom $c --steps 30 --warmup 5 --no-cpu-baseline --no-others 2>/dev/null | tail -1 | line
+echo "# tile order: 0 = one tile row per XCD (default); 3 / 4 / 5 = 2 / 4 / 8 consecutive tile rows per XCD, same box"
+for args in "--workload c2" "--workload c1" "--custom 1280x720:1920x1080:BILINEAR:RGB24:PLANAR:1" "--custom 960x540:1920x1080:BILINEAR:RGB24:PLANAR:1" "--workload headline" "--resize NEAREST" "--resize BICUBIC" "--workload c5" "--custom 1920x1080:1920x1080:NEAREST:RGB24:MERGED:0" "--custom 960x540:1920x1080:AREA:RGB24:MERGED:0" "--custom 1920x1080:1280x720:BILINEAR:RGB24:MERGED:0" "--custom 3840x2160:1920x1080:BILINEAR:RGB24:PLANAR:1"; do
+  for e in TSVPP_X=0 TSVPP_TILE_ORDER=3 TSVPP_TILE_ORDER=4 TSVPP_TILE_ORDER=5; do
+    printf "%-58s %-20s " "$args" "$e"; env $e python bench.py $args --steps 30 --warmup 5 --no-cpu-baseline --no-others 2>/dev/null | tail -1 | line
   done
 done
-} > gpurun_out/r05_u8_sc1_ab.txt 2>&1
+} > gpurun_out/r05_tile_groups_ab.txt 2>&1
