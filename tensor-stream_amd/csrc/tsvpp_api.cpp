@@ -767,8 +767,11 @@ int tsvpp_prepare_batch(tsvpp_ctx *ctx, const tsvpp_params *p, int in_width, int
         d.geo_build = 1;
         FrameTable t = {};
         const int total = n_frames > 0 ? n_frames : 1;
-        // the launch groups tsvpp_convert_batch forms: full groups of TSVPP_MAX_BATCH frames, then the remainder
-        const int groups[2] = { total >= TSVPP_MAX_BATCH ? TSVPP_MAX_BATCH : 0, total % TSVPP_MAX_BATCH };
+        // the launch groups tsvpp_convert_batch forms: full groups of TSVPP_MAX_BATCH frames, then the remainder; and, for more frames than that, the groups
+        // tsvpp_convert_table forms (up to TSVPP_MAX_TABLE_LAUNCH per launch; a launch the grid limit caps lower builds its tables on first use)
+        const int groups[4] = { total >= TSVPP_MAX_BATCH ? TSVPP_MAX_BATCH : 0, total % TSVPP_MAX_BATCH,
+                                total > TSVPP_MAX_BATCH ? (total < TSVPP_MAX_TABLE_LAUNCH ? total : TSVPP_MAX_TABLE_LAUNCH) : 0,
+                                total > TSVPP_MAX_TABLE_LAUNCH ? total % TSVPP_MAX_TABLE_LAUNCH : 0 };
         for (int cnt : groups) {
             if (cnt == 0) continue;
             d.n_frames = cnt;

@@ -148,3 +148,36 @@ def test_error_paths(vpp):
     assert L.tsvpp_convert_table(vpp._ctx, h_tab, 0, n, ctypes.byref(fp.parameters), stream) == 0
     torch.cuda.synchronize()
     L.tsvpp_table_destroy(h_tab)
+
+
+def test_a_table_conversion_is_hip_graph_capturable_and_replays_the_table_as_it_is_then(vpp, oracle):
+    """tsvpp_convert_table inside a hipGraph: after prepare() it is kernel launches only.  The kernels READ the table at run time, so a replay sees entries that
+    were replaced (stream-ordered) after the capture -- the pointer triples are not baked into the graph, unlike the kernarg table of tsvpp_convert_batch."""
+    import tensor_stream as ts
+    from tensor_stream import _native as N
+    w, h, n = 640, 360, 160
+    ys, uvs = _pool(w, h, w, n, seed=21)
+    fp = ts.FrameParameters(width=320, height=180, resize_type=1, pixel_format=1, planes_pos=0, normalization=True)
+    vpp.prepare(fp, w, h, n_frames=n)
+    tab = vpp.make_table(ys, uvs, fp, width=w)
+    out = tab["out"]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        vpp.run_table(tab, stream=side.cuda_stream)  # warm-up on the capture stream
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        vpp.run_table(tab, stream=side.cuda_stream)
+    # entry 5 now reads frame 150 (into output 5), set on the current stream; then replay
+    fr = (N.NV12 * 1)(vpp._frame(ys[150], uvs[150], w, None))
+    outs = (ctypes.c_void_p * 1)(out[5].data_ptr())
+    N.check(vpp._lib.tsvpp_table_set(tab["handle"], 5, 1, fr, outs, torch.cuda.current_stream().cuda_stream))
+    out.zero_()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    for f, src in ((0, 0), (5, 150), (159, 159)):
+        ref, _, _ = oracle.convert(ys[src].cpu().numpy(), uvs[src].cpu().numpy(), dst=(320, 180), resize_type=1, fourcc=1, planes=0, normalization=True, nthreads=8, width=w)
+        assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), (f, src)
+    del g
+    vpp.free_table(tab)
