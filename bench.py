@@ -636,7 +636,13 @@ class GpuEngine:
 
     def side_work(self, spec, sets=2, batch=None, table=False):
         """A second workload on the same context (other resize types of the headline, the 4K configurations): its own buffers."""
-        return GpuWork(self, spec, batch or self.args.batch, sets, 4321 + self.rank, table=table)
+        # enough rotating buffer sets that the leg's working set is >= 768 MiB, three times the Infinity Cache (C1's 64-frame set is 265 MB: two sets would half-fit)
+        B = batch or self.args.batch
+        src_w, src_h, pitch, crop, dst, _rt, fcc, _pl, norm = spec
+        _, _, dw, dh = roi_and_dst(src_w, src_h, crop, dst)
+        per_set = B * (pitch * src_h * 3 // 2 + int(dw * dh * {0: 1.0, 3: 1.5, 4: 2.0}.get(FOURCC[fcc], 3.0)) * (4 if (norm or fcc == "HSV") else 1))
+        sets = min(6, max(sets, -(-(768 << 20) // per_set)))
+        return GpuWork(self, spec, B, sets, 4321 + self.rank, table=table)
 
     def close(self):
         self.vpp.Close()
