@@ -203,16 +203,20 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
         // 16: one, two or four groups) -- into a ring of three batches of 1 KiB.  Lane addresses are loop-invariant up to the batch's
         // first row.  (The first version fetched 256 bytes per row whatever the ratio: 2.5 x the needed bytes at ratio 1.5, and the
         // launch ran 40 us longer than with its reads served from cache.)
-        const int L = SPARSE ? 16 : lanes_per_row, rpb = SPARSE ? 4 : 4 * (16 / L), gpb = rpb >> 2; // rows, groups per batch
+        // WIDE (round 5; dense mode, 17 .. 32 chunks per segment: horizontal ratios 3.7 .. 7.4, which took per-lane loads before): a batch is ONE group of four rows
+        // fetched by TWO instructions of two rows each, a ring slot is 4 L chunks
+        const bool wide = !SPARSE && lanes_per_row > 16;
+        const int L = SPARSE ? 16 : lanes_per_row, rpb = (SPARSE || wide) ? 4 : 4 * (16 / L), gpb = rpb >> 2; // rows, groups per batch
         const int xb0 = __builtin_amdgcn_readlane(xb, 0);
         const uint32_t seg0 = (pm + (uint32_t)xb0) & ~15u;           // the segment's first 16-byte chunk (byte column from `plane`)
         const uint32_t a_c = (uint32_t)(xb - xb0) + ((pm + (uint32_t)xb0) & 15u); // the lane's window start inside a ring row
         const uint32_t al_c = a_c & ~3u, sh_c = a_c & 3u, selx_c = STEP == 1 ? tapsel + rep4(sh_c) : tapsel;
         const uint32_t last_chunk = ((uint32_t)(rows_in_plane - 1) * (uint32_t)pitch + pm + (uint32_t)row_bytes - 1u) & ~15u; // the plane's last valid chunk
         const int lrow = (lane * (65536 / L + 1)) >> 16, lchunk = lane - lrow * L; // lane / L, lane % L (L <= 16, lane < 64: exact)
-        const bool lane_on = lrow < rpb;
+        const bool lane_on = wide ? lrow < 2 : lrow < rpb;
         const uint32_t lconst = seg0 + 16u * (uint32_t)lchunk + (SPARSE ? 0u : (uint32_t)lrow * (uint32_t)pitch);
         const int rstride = 16 * L; // ring row pitch
+        const int slot_bytes = wide ? 4 * rstride : 1024;
         const int nb = (ng + gpb - 1) / gpb;
         auto issue = [&](int bt, int slot) {
             uint32_t voff;
@@ -222,22 +226,36 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
             } else {
                 voff = (uint32_t)(ylo + rpb * bt) * (uint32_t)pitch + lconst; // rows past yhi are real rows of the plane (or clamped below): never used
             }
-            voff = min(voff, last_chunk);
-            uint8_t *dst = ring + slot * 1024; // wave-uniform
+            uint8_t *dst = ring + slot * slot_bytes; // wave-uniform
+            const uint32_t v0 = min(voff, last_chunk);
             if (lane_on)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane + v0), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            if constexpr (!SPARSE) {
+                if (wide) { // rows 2, 3 of the group: the second instruction, landing behind the first one's two rows
+                    const uint32_t v1 = min(voff + 2u * (uint32_t)pitch, last_chunk);
+                    if (lane_on)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane + v1),
+                                                         (__attribute__((address_space(3))) void *)(dst + 2 * rstride), 16, 0, 0);
+                }
+            }
         };
         issue(0, 0);
         if (nb > 1) issue(1, 1);
         if (nb > 2) issue(2, 2);
         int slot = 0, bt = 0, gin = 0; // ring slot and index of the current batch, group inside it
         for (int g = 0; g < ng; g++) {
-            if (gin == 0) { // batch bt has landed when at most the later batches' loads are outstanding (one per batch)
-                if (bt + 2 < nb) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (bt + 1 < nb) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gin == 0) { // batch bt has landed when at most the later batches' loads are outstanding (one per batch; WIDE: two)
+                if (wide) {
+                    if (bt + 2 < nb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (bt + 1 < nb) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    if (bt + 2 < nb) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (bt + 1 < nb) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
-            const uint8_t *p0 = ring + slot * 1024 + 4 * gin * rstride + al_c;
+            const uint8_t *p0 = ring + slot * slot_bytes + 4 * gin * rstride + al_c;
             uint32_t tp[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {

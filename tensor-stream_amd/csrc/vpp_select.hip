@@ -504,9 +504,13 @@ static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, Fus
         // at most 16 of them (horizontal ratios up to 3.68); bc_dma = chunks (lanes) per row; the kernel takes that path when the pitch is
         // a multiple of 16
         const int seg_bytes = (int)((double)d.xr * 63.0) + 2 + 7 + 15 + 1;
-        const bool dma = d.bc_dma_pref && seg_bytes <= 256;
+        // ... round 5: dense rows up to 32 chunks (ratios up to 7.4: 1080p -> 300 x 300, 4K -> 640 x 360) as two instructions per group of four rows ("wide", vpp_bicubic_cols.hip);
+        // TSVPP_BICUBIC_DMA=3 keeps the 16-chunk limit (per-lane loads beyond it: rounds 3-4)
+        // fp32 outputs only: 1080p -> 300 x 300 0.441 -> 0.471, -> 416 x 416 0.515 -> 0.558; uint8 merged LOSES 13 % (0.434 -> 0.378: the larger ring costs the occupancy its fewer
+        // bytes need; profiles/r05_bicubic_wide_ab.txt)
+        const bool dma = d.bc_dma_pref && (seg_bytes <= 256 || (!sparse && S.f32_out && seg_bytes <= 512 && d.bc_dma_pref != 3 && d.bc_dma_pref != 2));
         const int dma_lanes = (seg_bytes + 15) / 16 < 2 ? 2 : (seg_bytes + 15) / 16;
-        const int ring_bytes = dma ? 3 * 1024 + 16 : 0;
+        const int ring_bytes = dma ? (dma_lanes > 16 ? 3 * 64 * dma_lanes + 16 : 3 * 1024 + 16) : 0;
         auto col_stride = [&](int nout) { // bytes of one H-plane column: its dwords + one (phase 2 reads dword pairs), an odd number of them
             const int rows = sparse ? 4 * nout : (int)((double)d.yr * (nout - 1)) + 6;
             return 4 * ((((rows + 3) >> 2) + 1) | 1);
@@ -536,7 +540,7 @@ static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, Fus
             // tiles leave 48 / 32 of them idle and lose 3..5 % (profiles/r05_bicubic_cols_u8_ab.txt).  TSVPP_BICUBIC_U8X=2: every tile height, 0: never.
             d.bc_u8x = (d.bc_u8x_pref && (d.dst_w & 7) == 0 && (d.dst_h & 3) == 0 && (best_r == 32 || d.bc_u8x_pref == 2)) ? 1 : 0;
             d.bc_sparse = sparse ? 1 : 0;
-            d.bc_dma = dma ? (d.bc_dma_pref > 1 ? 16 : dma_lanes) : 0; // TSVPP_BICUBIC_DMA=2: 256-byte segments whatever the ratio (A/B)
+            d.bc_dma = dma ? (d.bc_dma_pref == 2 ? 16 : dma_lanes) : 0; // TSVPP_BICUBIC_DMA=2: 256-byte segments whatever the ratio (A/B)
             d.bc_ring_bytes = ring_bytes;
             d.bc_npy = bicubic_cols_rows_padded(d.dst_h);
             d.bc_npc = bicubic_cols_rows_padded(d.dst_h >> 1);

@@ -42,7 +42,7 @@ TIE_DENSE, TIE_SPARSE = "vpp_bicubic_cols_kernel<OUT,tie,dense>", "vpp_bicubic_c
     ((1280, 720), (1920, 1080), TIE_DENSE),   # 0.667 up-scale: 5 chunks, twelve rows per instruction, 32-row tiles
     ((640, 360), (1600, 900), TIE_DENSE),     # 0.4 up-scale: 3 chunks, sixteen rows per instruction
     ((1920, 1080), (640, 640), TIE_DENSE),    # 3.0 (all weights 0: the point kernel) x 1.6875 -> mixed: stays bicubic
-    ((1920, 1080), (300, 300), TIE_DENSE),    # 6.4 x 3.6: per-lane loads (a segment would exceed 256 bytes), dense rows
+    ((1920, 1080), (300, 300), TIE_DENSE),    # 6.4 x 3.6: 27 chunks per segment -- fp32 outputs: LDS-DMA, two instructions per group of four rows (round 5); uint8: per-lane loads
     ((1920, 1080), (224, 224), TIE_SPARSE),   # 8.57 x 4.82: per-lane loads, only the tapped rows
     ((1080, 1920), (480, 224), TIE_SPARSE),   # 2.25 x 8.57: LDS-DMA with one output row's four taps per instruction
     ((3840, 2160), (854, 480), TIE_SPARSE),   # 4.5 x 4.5: dyadic? no: 3840 / 854 is not -- and dst_w = 4 k + 2 (row-tail launch)

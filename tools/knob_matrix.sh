@@ -21,6 +21,7 @@ TSVPP_BICUBIC_COLS=2
 TSVPP_BICUBIC_COLS=0
 TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=0
 TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=2
+TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=3
 TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_ROWS=8
 TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_ROWS=32
 TSVPP_RPT=1
