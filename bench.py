@@ -61,7 +61,8 @@ WORKLOADS = {
 # frames per step and "out of a persistent frame table" when --batch is not given.  C3 moves 1.8 MB per frame and C4 6.9 MB: their 64-frame launches (113 / 442 MB) run at
 # 0.64 / 0.64 of the roofline on moved bytes, 0.72 / 0.67 from 512 / 256 frames on (profiles/r05_table_ab.txt, r05_c4_shapes.txt); the headline and the other
 # configurations gain nothing (or lose: 1024-frame launches of the headline 0.775 -> 0.711) and keep 64
-DEFAULT_BATCH = {"c3": (512, True), "c4": (256, True)}
+# C1's frames are small too (4.1 MB): 128 frames per launch -- still the kernarg path -- 0.68 -> 0.73 (profiles/r05_c1_batch.txt); a table adds nothing beyond that
+DEFAULT_BATCH = {"c1": (128, False), "c3": (512, True), "c4": (256, True)}
 RESIZE = {"NEAREST": 0, "BILINEAR": 1, "BICUBIC": 2, "AREA": 3}
 FOURCC = {"Y800": 0, "RGB24": 1, "BGR24": 2, "NV12": 3, "UYVY": 4, "YUV444": 5, "HSV": 6}
 PLANES = {"PLANAR": 0, "MERGED": 1}

@@ -1,30 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/r05_gpu_suite.txt
-KNOBS="TSVPP_BICUBIC_COLS=2
-TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=0
-TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=2
-TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_DMA=3
-TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_ROWS=8
-TSVPP_BICUBIC_COLS=2 TSVPP_BICUBIC_ROWS=32
-TSVPP_BICUBIC_INT=2
-TSVPP_BILINEAR_INT=2
-TSVPP_BILINEAR_ROWS_WAVES=1
-TSVPP_BICUBIC_U8X=2
-TSVPP_RPT=1
-TSVPP_RPT=3
-TSVPP_AREA_DIRECT_MIN=2
-TSVPP_AREA_DIRECT_MIN=100
-TSVPP_SHAPE=16,4
-TSVPP_SHAPE=64,4
-TSVPP_SHAPE=128,2
-TSVPP_AREA_COLS=0
-TSVPP_AREA_COLS=2
-TSVPP_AREA_COLS_ROWS=8
-TSVPP_AREA_COLS_ROWS=32
-TSVPP_AREA_DIVTAB=0
-TSVPP_AREA_STREAM=0
-TSVPP_TILE_ORDER=2
-TSVPP_TILE_ORDER=3
-TSVPP_TILE_ORDER=5
-TSVPP_GEO=2" bash tools/knob_matrix.sh > gpurun_out/r05_knob_matrix_rest.txt 2>&1
+bash tools/profile.sh c1 --workload c1 > /dev/null 2>&1
