@@ -90,6 +90,18 @@ def test_unsupported_and_error_statuses(native):
     assert native.lib().tsvpp_out_bytes(ctypes.byref(P(native, fourcc=9)), 640, 360) == 0
 
 
+def test_table_and_trim_entry_points_reject_null_arguments_without_a_gpu(native):
+    """The round-5 entry points (persistent frame tables, tsvpp_trim) check their arguments before they touch a device: callable here, status VREADER_ERROR."""
+    L = native.lib()
+    h = ctypes.c_void_p()
+    p = P(native, fourcc=1)
+    assert L.tsvpp_table_create(None, 8, ctypes.byref(h)) == -3 and not h.value
+    assert L.tsvpp_table_set(None, 0, 1, None, None, None) == -3
+    assert L.tsvpp_convert_table(None, None, 0, 1, ctypes.byref(p), None) == -3
+    assert L.tsvpp_trim(None, None) == -3
+    L.tsvpp_table_destroy(None)  # a no-op, like free(NULL)
+
+
 def test_channels(native, oracle):
     for f in range(7):
         assert native.lib().tsvpp_channels(f) == oracle.channels(f)
