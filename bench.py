@@ -263,6 +263,96 @@ def latency_leg(spec, iters=2000):
     return json.loads(lines[-1])
 
 
+def curve_frame(frame_id, pitch, src_h):
+    """Pool frame `frame_id` of tensor-stream_amd/cpp/vpp_curve.cpp, regenerated on the host: byte i of plane p = lowbias32(i + id * 0x9E3779B1 + p * 0x85EBCA6B) >> 24."""
+    def plane(n, pl):
+        x = np.arange(n, dtype=np.uint32) + np.uint32((frame_id * 0x9E3779B1 + pl * 0x85EBCA6B) & 0xFFFFFFFF)
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+        return (x >> np.uint32(24)).astype(np.uint8)
+    return plane(pitch * src_h, 0).reshape(src_h, pitch), plane(pitch * src_h // 2, 1).reshape(src_h // 2, pitch)
+
+
+CURVE_NS = (1, 2, 4, 8, 16, 32, 64)
+# consumer shapes of the launch curve: threads x streams per thread (vpp_curve.cpp) -> key in the line
+CURVE_MODES = (("1x1", "one_consumer"), ("4x1", "four_consumers"))
+
+
+def launch_curve_leg(names=("headline", "c3", "c4"), ns=CURVE_NS, modes=CURVE_MODES, target_ms=30.0, inputs_ready=(0, 1), parity=True):
+    """the hot path at the launch sizes the reference's calling pattern produces -- ONE frame per Convert (reference
+    src/Wrappers/WrapperPython.cpp:265-363) out of a ring of 5-10 frames (include/Decoder.h:19) -- i.e. 1 .. 64 frames per launch, on rotating pools whose moved bytes
+    exceed 640 MiB per issuing thread (tensor-stream_amd/cpp/vpp_curve.cpp, its own process, after the timed region).  Per workload and n:
+      one_consumer     every launch on ONE stream, back to back (HIP events on that stream; the dependent-launch boundary is inside the figure);
+      four_consumers   four host threads, each with its own stream (the reference's model: one stream per consumer name), wall clock over all launches;
+      *_inputs_ready   the same with TSVPP_OPT_INPUTS_READY (include/tsvpp.h): launches do not wait for their predecessors on the stream.
+    `frac` = moved bytes per launch / time per launch / 8 TB/s; moved bytes = the ROI formula, or for the sparse samplers (C3, C4) the PMC traffic per frame of the
+    profiled launch when that entry is fresh, else the touched bytes (a lower bound).  Every point is checked against the oracle: CRC-32 of the first and the last
+    output frame of the last launch (the pool's outputs are overwritten before every point)."""
+    import zlib
+    exe = os.path.join(ROOT, "tensor-stream_amd", "lib", "vpp_curve")
+    if not os.path.isfile(exe):
+        return {"error": "tensor-stream_amd/lib/vpp_curve is not built (make -C tensor-stream_amd/cpp)"}
+    from oracle import oracle as O
+    res = {"n": list(ns), "driver": "tensor-stream_amd/cpp/vpp_curve.cpp", "pool": "> 640 MiB of moved bytes per issuing thread, rotating"}
+    for name in names:
+        spec = WORKLOADS[name]
+        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+        bpf = algorithmic_bytes(src_w, src_h, crop, dst, norm)
+        wbs = bpf - roi_and_dst(src_w, src_h, crop, dst)[0] * roi_and_dst(src_w, src_h, crop, dst)[1] * 3 // 2
+        moved, basis = bpf, "algorithmic bytes (ROI formula)"
+        tbs = touched_bytes(spec)
+        if tbs < 0.9 * bpf:
+            moved, basis = tbs, "touched bytes (sparse sampler: a lower bound of the bytes moved)"
+            try:
+                fpl = float(DEFAULT_BATCH.get(name, (64, False))[0])
+                tr, _why = lookup_traffic(name, fpl, alg_read=(bpf - wbs) * fpl, alg_write=wbs * fpl, touched_read=(tbs - wbs) * fpl)
+                if tr:
+                    moved, basis = tr / fpl, "PMC traffic per frame of the profiled %d-frame launch" % int(fpl)
+            except Exception:  # noqa: BLE001
+                pass
+        entry = {"workload": name, "moved_bytes_per_frame": int(moved), "basis": basis}
+        bad = []
+        for ready in inputs_ready:
+            cmd = [exe, str(src_w), str(src_h), str(pitch), *(str(c) for c in crop), str(dst[0]), str(dst[1]), str(RESIZE[rt]), str(FOURCC[fcc]), str(PLANES[planes]),
+                   "1" if norm else "0", str(int(moved)), ",".join(str(n) for n in ns), ",".join(m for m, _ in modes), str(target_ms), str(ready)]
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not lines:
+                entry["error"] = f"vpp_curve exited {pr.returncode}: {pr.stderr[-300:]}"
+                break
+            out = json.loads(lines[-1])
+            entry["pool_frames_per_thread"] = out["pool_frames_per_thread"]
+            for mode, key in modes:
+                t, st = (int(x) for x in mode.split("x"))
+                pts = [q for q in out["points"] if q["threads"] == t and q["streams_per_thread"] == st]
+                pts.sort(key=lambda q: q["n"])
+                k = key + ("_inputs_ready" if ready else "")
+                entry[k] = {"us_per_launch": [round(q["us_per_launch"], 3) for q in pts],
+                            "frac": [round(moved * q["n"] / (q["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) for q in pts],
+                            "frames_per_s": [round(q["n"] / (q["us_per_launch"] * 1e-6), 1) for q in pts],
+                            "host_issue_us_per_launch": [round(q["host_issue_us_per_launch"], 2) for q in pts], "timer": pts[0]["timer"] if pts else None}
+                if parity:
+                    for q in pts:
+                        for c in q["check"]:
+                            y, uv = curve_frame(c["frame"], pitch, src_h)
+                            ref, _, _ = O.convert(y, uv, crop=crop, dst=dst, resize_type=RESIZE[rt], fourcc=FOURCC[fcc], planes=PLANES[planes], normalization=norm,
+                                                  nthreads=min(16, O.host_cores()), width=src_w)
+                            if (zlib.crc32(ref.tobytes()) & 0xFFFFFFFF) != c["crc32"]:
+                                bad.append(f"{k} n={q['n']} frame {c['frame']}")
+        if "error" not in entry:
+            entry["parity"] = ("not checked" if not parity else ("MISMATCH vs oracle: " + ", ".join(bad[:6])) if bad else
+                               "bit-exact vs oracle (CRC-32 of the first and last output frame of the last launch, every point)")
+            if bad:
+                for _mode, key in modes:  # a fast wrong kernel is not a measurement
+                    for ready in inputs_ready:
+                        entry.pop(key + ("_inputs_ready" if ready else ""), None)
+        res[name] = entry
+    return res
+
+
 _SHARED_SOURCES = ["tensor-stream_amd/csrc/vpp_device.h", "tensor-stream_amd/csrc/vpp_kernels.h", "tensor-stream_amd/csrc/vpp_axis.h"]
 _KERNEL_FILES = [("vpp_bilinear_r32", "vpp_bilinear_r32.hip"), ("vpp_bilinear_up2", "vpp_bilinear_up2.hip"), ("vpp_bilinear_rows", "vpp_bilinear_rows.hip"), ("vpp_point_rn", "vpp_point_rn.hip"),
                  ("vpp_bilinear", "vpp_bilinear.hip"), ("vpp_bicubic_r32", "vpp_bicubic_r32.hip"), ("vpp_bicubic_int", "vpp_bicubic_int.hip"),
@@ -365,6 +455,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true", help="skip the NEAREST/BICUBIC/AREA side measurements of the headline")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--warmup-ms", type=float, default=40.0, help="time-based warm-up after the --warmup steps: untimed steps until the device has worked this long (clock ramp)")
+    ap.add_argument("--curve-only", default=None, help="run only the launch-curve leg (1 .. 64 frames per launch, tensor-stream_amd/cpp/vpp_curve.cpp) for these workloads, "
+                    "comma separated (e.g. headline,c3,c4), print its JSON and exit")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to the CPUs local to its GPU")
     return ap.parse_args(argv)
 
@@ -1048,6 +1140,10 @@ def run(args):
                 res["config"]["latency"] = latency_leg(spec)
             except Exception as e:
                 res["config"]["latency"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                res["config"]["launch_curve"] = launch_curve_leg()
+            except Exception as e:
+                res["config"]["launch_curve"] = {"error": f"{type(e).__name__}: {e}"}
         if others is not None:
             res["config"]["other_resize_types"] = others
         if other_wl is not None:
@@ -1072,6 +1168,9 @@ def run(args):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.curve_only:
+        print(json.dumps(launch_curve_leg(tuple(args.curve_only.split(",")), parity=not args.no_parity)), flush=True)
+        return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn(args, argv)
     return run(args)

@@ -172,6 +172,24 @@ int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes);
  * libroctx64) is looked up at run time; TSVPP_UNSUPPORTED if neither is installed. */
 int tsvpp_enable_markers(tsvpp_ctx *ctx, int on);
 
+/* ---- context options (round 6; not in the reference) -----------------------------------------------------------------------------------------------
+ * TSVPP_OPT_INPUTS_READY (default 0).  The reference's getFrame hands a consumer a frame the decoder has FINISHED (Decoder::GetFrame blocks on a condition
+ * variable until the decode thread publishes it, reference src/Decoder.cpp:97-131) and converts it into a buffer nobody else uses; its consumer streams
+ * carry nothing but conversions (src/VideoProcessor.cpp:98-104).  A pipeline with that shape may set this option: every fused launch of the context then goes
+ * out with the AQL barrier bit cleared (hipExtAnyOrderLaunch) -- it does not wait for work enqueued EARLIER on its stream, so back-to-back single-frame
+ * conversions of one consumer overlap instead of paying a dependent-launch boundary each (~1.5-1.9 us against ~2.3 us of HBM time for a 1080p -> 720p frame).
+ * The caller promises, for every conversion while the option is set:
+ *   (1) the input planes are complete in device memory when the call is made (not merely enqueued earlier on `stream`);
+ *   (2) nothing enqueued earlier on `stream` still reads or writes the output buffer.
+ * What stays ordered: anything enqueued LATER on the stream (events, copies, other kernels, synchronisation) still waits for the conversion; the two-pass
+ * formats (UYVY / YUV444 where no single-pass kernel applies) and launches out of a tsvpp_table never use the option (their scratch buffer / table upload
+ * are ordered by the stream).
+ * Results are identical either way. */
+#define TSVPP_OPT_INPUTS_READY 1
+#define TSVPP_HAVE_OPTIONS 1
+int tsvpp_set_option(tsvpp_ctx *ctx, int option, int value);
+int tsvpp_get_option(const tsvpp_ctx *ctx, int option, int *value);
+
 /* Colour constants: read the active block, replace it (e.g. with the block received
  * from rank 0), restore the defaults. */
 int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out);

@@ -268,6 +268,7 @@ struct tsvpp_ctx {
     std::vector<uint8_t *> retired;
     std::mutex scratch_mu;
     int markers = 0; // tsvpp_enable_markers: roctx ranges around every conversion (the reference's NVTX ranges)
+    int inputs_ready = 0; // TSVPP_OPT_INPUTS_READY: fused launches do not wait for earlier work on their stream (include/tsvpp.h)
 };
 
 namespace {
@@ -908,6 +909,9 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // Frames per launch: TSVPP_MAX_BATCH with the pointer triples in the kernarg segment; out of a device-resident table (single-pass requests) up to
     // TSVPP_MAX_TABLE_LAUNCH, less where the grid would outgrow 2^31 threads (the smallest tile any kernel uses is 64 x 4 output pixels per workgroup of 256).
     const bool from_table = tab.y != nullptr && !two_pass;
+    // TSVPP_OPT_INPUTS_READY: never out of a table (tsvpp_table_set's upload is enqueued on this stream: the launch must wait for it), never for the two-pass
+    // formats (pass 1 writes the stream's scratch buffer, which the previous call's pass 2 may still be reading)
+    d.any_order = (ctx->inputs_ready && tab.y == nullptr && !two_pass) ? 1 : 0;
     int max_launch = TSVPP_MAX_BATCH;
     if (from_table) {
         const long wg_per_frame = (long)((pl.dst_w + 63) / 64) * ((pl.dst_h + 3) / 4);
@@ -1079,6 +1083,22 @@ int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes) {
     }
     if (released_bytes) *released_bytes = n;
     return TSVPP_OK;
+}
+
+int tsvpp_set_option(tsvpp_ctx *ctx, int option, int value) {
+    if (!ctx) return TSVPP_ERROR;
+    switch (option) {
+    case TSVPP_OPT_INPUTS_READY: ctx->inputs_ready = value ? 1 : 0; return TSVPP_OK;
+    default: return TSVPP_UNSUPPORTED;
+    }
+}
+
+int tsvpp_get_option(const tsvpp_ctx *ctx, int option, int *value) {
+    if (!ctx || !value) return TSVPP_ERROR;
+    switch (option) {
+    case TSVPP_OPT_INPUTS_READY: *value = ctx->inputs_ready; return TSVPP_OK;
+    default: return TSVPP_UNSUPPORTED;
+    }
 }
 
 int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out) {

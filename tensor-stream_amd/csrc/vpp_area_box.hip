@@ -165,7 +165,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_box_kernel(const LaunchD
 template <int RX, bool SQUARE>
 static hipError_t launch_box_rs(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
-#define TSVPP_BOX(O) case O: hipLaunchKernelGGL((vpp_area_box_kernel<RX, SQUARE, O>), grid, block, 0, stream, d, t); break;
+#define TSVPP_BOX(O) case O: TSVPP_LAUNCH((vpp_area_box_kernel<RX, SQUARE, O>), grid, block, 0, stream, d, t); break;
         TSVPP_BOX(O_U8_PLANAR) TSVPP_BOX(O_U8_MERGED) TSVPP_BOX(O_F32_PLANAR) TSVPP_BOX(O_F32_MERGED) TSVPP_BOX(O_NV12_U8)
         TSVPP_BOX(O_NV12_F32) TSVPP_BOX(O_Y800_U8) TSVPP_BOX(O_Y800_F32) TSVPP_BOX(O_HSV_F32)
 #undef TSVPP_BOX

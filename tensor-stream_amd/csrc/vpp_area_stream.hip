@@ -283,7 +283,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_stream_kernel(const Laun
 template <int NK>
 static hipError_t launch_area_stream_nk(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, size_t lds, hipStream_t stream) {
     switch (out) {
-#define TSVPP_AS(O) case O: hipLaunchKernelGGL((vpp_area_stream_kernel<NK, O>), grid, dim3(MAX_THREADS), lds, stream, d, t); break;
+#define TSVPP_AS(O) case O: TSVPP_LAUNCH((vpp_area_stream_kernel<NK, O>), grid, dim3(MAX_THREADS), lds, stream, d, t); break;
         TSVPP_AS(O_U8_PLANAR) TSVPP_AS(O_U8_MERGED) TSVPP_AS(O_F32_PLANAR) TSVPP_AS(O_F32_MERGED) TSVPP_AS(O_NV12_U8)
         TSVPP_AS(O_NV12_F32) TSVPP_AS(O_Y800_U8) TSVPP_AS(O_Y800_F32) TSVPP_AS(O_HSV_F32)
 #undef TSVPP_AS

@@ -571,10 +571,10 @@ hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, con
     switch (out) {
 #define TSVPP_BC(O)                                                                                                               \
     case O:                                                                                                                       \
-        if (exact && sparse) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true, true>), grid, block, lds_bytes, stream, d, t);   \
-        else if (exact) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, true, false>), grid, block, lds_bytes, stream, d, t);       \
-        else if (sparse) hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false, true>), grid, block, lds_bytes, stream, d, t);      \
-        else hipLaunchKernelGGL((vpp_bicubic_cols_kernel<O, false, false>), grid, block, lds_bytes, stream, d, t);                 \
+        if (exact && sparse) TSVPP_LAUNCH((vpp_bicubic_cols_kernel<O, true, true>), grid, block, lds_bytes, stream, d, t);   \
+        else if (exact) TSVPP_LAUNCH((vpp_bicubic_cols_kernel<O, true, false>), grid, block, lds_bytes, stream, d, t);       \
+        else if (sparse) TSVPP_LAUNCH((vpp_bicubic_cols_kernel<O, false, true>), grid, block, lds_bytes, stream, d, t);      \
+        else TSVPP_LAUNCH((vpp_bicubic_cols_kernel<O, false, false>), grid, block, lds_bytes, stream, d, t);                 \
         break;
         TSVPP_BC(O_U8_PLANAR) TSVPP_BC(O_U8_MERGED) TSVPP_BC(O_F32_PLANAR) TSVPP_BC(O_F32_MERGED) TSVPP_BC(O_NV12_U8)
         TSVPP_BC(O_NV12_F32) TSVPP_BC(O_Y800_U8) TSVPP_BC(O_Y800_F32) TSVPP_BC(O_HSV_F32)

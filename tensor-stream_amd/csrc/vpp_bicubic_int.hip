@@ -264,7 +264,7 @@ hipError_t launch_bicubic_int(OutKind out, const LaunchDesc &d, const FrameTable
         return hipSuccess;
     }
     switch (out) {
-#define TSVPP_BI(O) case O: hipLaunchKernelGGL((vpp_bicubic_int_kernel<O>), grid, block, lds_bytes, stream, d, t); break;
+#define TSVPP_BI(O) case O: TSVPP_LAUNCH((vpp_bicubic_int_kernel<O>), grid, block, lds_bytes, stream, d, t); break;
         TSVPP_BI(O_U8_PLANAR) TSVPP_BI(O_U8_MERGED) TSVPP_BI(O_F32_PLANAR) TSVPP_BI(O_F32_MERGED) TSVPP_BI(O_NV12_U8)
         TSVPP_BI(O_NV12_F32) TSVPP_BI(O_Y800_U8) TSVPP_BI(O_Y800_F32) TSVPP_BI(O_HSV_F32)
 #undef TSVPP_BI

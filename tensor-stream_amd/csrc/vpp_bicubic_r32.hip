@@ -108,7 +108,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_r32_kernel(const Laun
 
 template <int P2> static hipError_t launch_bcr_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
-#define TSVPP_BCR(O) case O: hipLaunchKernelGGL((vpp_bicubic_r32_kernel<O, P2>), grid, block, 0, stream, d, t); break;
+#define TSVPP_BCR(O) case O: TSVPP_LAUNCH((vpp_bicubic_r32_kernel<O, P2>), grid, block, 0, stream, d, t); break;
         TSVPP_BCR(O_U8_PLANAR) TSVPP_BCR(O_U8_MERGED) TSVPP_BCR(O_F32_PLANAR) TSVPP_BCR(O_F32_MERGED) TSVPP_BCR(O_NV12_U8) TSVPP_BCR(O_NV12_F32)
         TSVPP_BCR(O_Y800_U8) TSVPP_BCR(O_Y800_F32) TSVPP_BCR(O_HSV_F32)
 #undef TSVPP_BCR

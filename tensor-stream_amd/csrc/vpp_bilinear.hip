@@ -693,8 +693,8 @@ static hipError_t launch_bilinear_geo(OutKind out, const LaunchDesc &d, const Fr
     switch (out) {
 #define TSVPP_GEO(O)                                                                                      \
     case O:                                                                                               \
-        if (d.tx >= 64) hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O, true>), grid, block, lds, stream, d, t); \
-        else hipLaunchKernelGGL((vpp_bilinear_geo_kernel<O, false>), grid, block, lds, stream, d, t);     \
+        if (d.tx >= 64) TSVPP_LAUNCH((vpp_bilinear_geo_kernel<O, true>), grid, block, lds, stream, d, t); \
+        else TSVPP_LAUNCH((vpp_bilinear_geo_kernel<O, false>), grid, block, lds, stream, d, t);     \
         break;
         TSVPP_GEO(O_U8_PLANAR) TSVPP_GEO(O_U8_MERGED) TSVPP_GEO(O_F32_PLANAR) TSVPP_GEO(O_F32_MERGED) TSVPP_GEO(O_NV12_U8)
         TSVPP_GEO(O_NV12_F32) TSVPP_GEO(O_Y800_U8) TSVPP_GEO(O_Y800_F32) TSVPP_GEO(O_HSV_F32)
@@ -709,7 +709,7 @@ static hipError_t launch_bilinear_a(OutKind out, const LaunchDesc &d, const Fram
     switch (out) {
 #define TSVPP_BIL(O)                                                                                                            \
     case O:                                                                                                                     \
-        hipLaunchKernelGGL((vpp_bilinear_kernel<AREAUP, O>), grid, block, lds, stream, d, t);                                   \
+        TSVPP_LAUNCH((vpp_bilinear_kernel<AREAUP, O>), grid, block, lds, stream, d, t);                                   \
         break;
         TSVPP_BIL(O_U8_PLANAR) TSVPP_BIL(O_U8_MERGED) TSVPP_BIL(O_F32_PLANAR) TSVPP_BIL(O_F32_MERGED) TSVPP_BIL(O_NV12_U8)
         TSVPP_BIL(O_NV12_F32) TSVPP_BIL(O_Y800_U8) TSVPP_BIL(O_Y800_F32) TSVPP_BIL(O_HSV_F32)

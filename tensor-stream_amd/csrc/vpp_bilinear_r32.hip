@@ -454,7 +454,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
 template <int KIND, int P2>
 static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
-#define TSVPP_R32(O) case O: hipLaunchKernelGGL((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
+#define TSVPP_R32(O) case O: TSVPP_LAUNCH((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
         TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8) TSVPP_R32(O_YUV444_U8)
         TSVPP_R32(O_F32_PLANAR) TSVPP_R32(O_F32_MERGED) TSVPP_R32(O_NV12_F32) TSVPP_R32(O_Y800_F32) TSVPP_R32(O_HSV_F32)
 #undef TSVPP_R32

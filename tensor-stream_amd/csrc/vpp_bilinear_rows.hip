@@ -211,8 +211,8 @@ hipError_t launch_bilinear_rows(OutKind out, const LaunchDesc &d, const FrameTab
     switch (out) {
 #define TSVPP_BR(O)                                                                                                     \
     case O:                                                                                                             \
-        if (wx0) hipLaunchKernelGGL((vpp_bilinear_rows_kernel<O, true>), grid, block, lds_bytes, stream, d, t);          \
-        else hipLaunchKernelGGL((vpp_bilinear_rows_kernel<O, false>), grid, block, lds_bytes, stream, d, t);             \
+        if (wx0) TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, true>), grid, block, lds_bytes, stream, d, t);          \
+        else TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, false>), grid, block, lds_bytes, stream, d, t);             \
         break;
         TSVPP_BR(O_U8_PLANAR) TSVPP_BR(O_U8_MERGED) TSVPP_BR(O_F32_PLANAR) TSVPP_BR(O_F32_MERGED) TSVPP_BR(O_NV12_U8)
         TSVPP_BR(O_NV12_F32) TSVPP_BR(O_Y800_U8) TSVPP_BR(O_Y800_F32) TSVPP_BR(O_HSV_F32)

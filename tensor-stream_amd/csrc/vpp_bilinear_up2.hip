@@ -105,7 +105,7 @@ hipError_t launch_bilinear_up2(OutKind out, const LaunchDesc &d, const FrameTabl
         return hipSuccess;
     }
     switch (out) {
-#define TSVPP_U2(O) case O: hipLaunchKernelGGL((vpp_bilinear_up2_kernel<O>), grid, block, 0, stream, d, t); break;
+#define TSVPP_U2(O) case O: TSVPP_LAUNCH((vpp_bilinear_up2_kernel<O>), grid, block, 0, stream, d, t); break;
         TSVPP_U2(O_U8_PLANAR) TSVPP_U2(O_U8_MERGED) TSVPP_U2(O_F32_PLANAR) TSVPP_U2(O_F32_MERGED) TSVPP_U2(O_NV12_U8) TSVPP_U2(O_NV12_F32)
         TSVPP_U2(O_Y800_U8) TSVPP_U2(O_Y800_F32) TSVPP_U2(O_HSV_F32)
 #undef TSVPP_U2

@@ -2,6 +2,7 @@
 // (vpp_kernels.hip).  Product code -- never includes anything from oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -166,8 +167,18 @@ struct LaunchDesc {
     // row segment (<= 64), 0 = off; br_waves: waves (64-column tiles) per workgroup; br_rpi: segments per DMA instruction (64 / bil_rows).  A wave's LDS bytes travel in bc_wave_bytes.
     int bil_rows_pref, bil_rows, br_waves, br_rpi;
     int point_rn_pref; // TSVPP_POINT_RN: streaming point sampler at exact integer ratios (vpp_point_rn.hip) allowed; chosen: r32 >= 100
+    // TSVPP_OPT_INPUTS_READY (include/tsvpp.h): the launch does not wait for work enqueued earlier on its stream -- its AQL packet goes out with the barrier bit
+    // cleared (hipExtAnyOrderLaunch), so the dependent-launch boundary (~1.5-1.9 us between streaming kernels) overlaps the predecessor's drain.  Host-side only.
+    int any_order;
     GeoCache *geo_cache;
 };
+
+// Every fused-kernel launch goes through this: an ordinary in-order launch, or -- LaunchDesc::any_order -- one whose packet does not wait for its predecessors.
+#define TSVPP_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, D, T)                                                                         \
+    do {                                                                                                                             \
+        if ((D).any_order) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (uint32_t)(LDS), STREAM, nullptr, nullptr, hipExtAnyOrderLaunch, D, T); \
+        else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, D, T);                                                             \
+    } while (0)
 
 //  everything a kernel receives travels in the kernarg segment: 4 KiB, of which HIP's hidden arguments take up to 256 bytes
 static_assert(sizeof(LaunchDesc) + sizeof(FrameTable) + 256 <= 4096, "LaunchDesc + FrameTable no longer fit the kernarg segment");

@@ -916,14 +916,14 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_color_kernel(const LaunchDesc
 
 // Launch, or -- when the caller only wants to know what WOULD run (tsvpp_describe, CPU tests of the selection
 // logic) -- record the choice and launch nothing.
-#define TSVPP_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS)                                   \
+#define TSVPP_LAUNCH_OR_DESCRIBE(NAME, KERNEL, GRID, BLOCK, LDS)                                   \
     do {                                                                               \
         if (info) {                                                                    \
             info->kernel = NAME;                                                       \
             info->grid = (int)(GRID).x;                                                \
             info->lds_bytes = (int)(LDS);                                              \
         } else {                                                                       \
-            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, stream, d, t);                \
+            TSVPP_LAUNCH(KERNEL, GRID, BLOCK, LDS, stream, d, t);                \
         }                                                                              \
     } while (0)
 
@@ -931,9 +931,9 @@ template <int OUT>
 static hipError_t launch_point(const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(d.tx * d.ty));
     switch (d.point_kind) {
-    case PK_NEAREST: TSVPP_LAUNCH("vpp_point_kernel<PK_NEAREST, OUT>", (vpp_point_kernel<PK_NEAREST, OUT>), grid, block, lds_bytes); break;
-    case PK_BILINEAR0: TSVPP_LAUNCH("vpp_point_kernel<PK_BILINEAR0, OUT>", (vpp_point_kernel<PK_BILINEAR0, OUT>), grid, block, lds_bytes); break;
-    case PK_BICUBIC0: TSVPP_LAUNCH("vpp_point_kernel<PK_BICUBIC0, OUT>", (vpp_point_kernel<PK_BICUBIC0, OUT>), grid, block, lds_bytes); break;
+    case PK_NEAREST: TSVPP_LAUNCH_OR_DESCRIBE("vpp_point_kernel<PK_NEAREST, OUT>", (vpp_point_kernel<PK_NEAREST, OUT>), grid, block, lds_bytes); break;
+    case PK_BILINEAR0: TSVPP_LAUNCH_OR_DESCRIBE("vpp_point_kernel<PK_BILINEAR0, OUT>", (vpp_point_kernel<PK_BILINEAR0, OUT>), grid, block, lds_bytes); break;
+    case PK_BICUBIC0: TSVPP_LAUNCH_OR_DESCRIBE("vpp_point_kernel<PK_BICUBIC0, OUT>", (vpp_point_kernel<PK_BICUBIC0, OUT>), grid, block, lds_bytes); break;
     default: return hipErrorInvalidValue;
     }
     return info ? hipSuccess : hipGetLastError();
@@ -970,65 +970,65 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
             if (vec && d.area_direct == 1 && d.area_box && !d.force_gather) // integer ratio: contiguous dword runs
                 return launch_area_box((OutKind)OUT, d, t, stream, info);
             if (vec && d.area_direct == 1 && d.qx && d.qy && !d.force_gather) { // large dyadic ratios: no LDS at all
-                if (d.rx <= 4) TSVPP_LAUNCH("vpp_area_direct_kernel<1, OUT>", (vpp_area_direct_kernel<1, OUT>), grid, block, 0);
-                else TSVPP_LAUNCH("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
+                if (d.rx <= 4) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_direct_kernel<1, OUT>", (vpp_area_direct_kernel<1, OUT>), grid, block, 0);
+                else TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_direct_kernel<2, OUT>", (vpp_area_direct_kernel<2, OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
             if (vec && d.area_direct == 2 && d.area_cols && !d.force_gather) { // one output column per lane, taps straight from global memory
                 const dim3 cblock(MAX_THREADS); // 256 threads whatever the tile height
                 if (d.area_cols_rows == 32) {
-                    if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 32, OUT>", (vpp_area_cols_kernel<2, 32, OUT>), grid, cblock, 0);
-                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
+                    if (d.nkx == 1) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<1, 32, OUT>", (vpp_area_cols_kernel<1, 32, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<2, 32, OUT>", (vpp_area_cols_kernel<2, 32, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<3, 32, OUT>", (vpp_area_cols_kernel<3, 32, OUT>), grid, cblock, 0);
                 } else {
-                    if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_cols_kernel<1, 8, OUT>", (vpp_area_cols_kernel<1, 8, OUT>), grid, cblock, 0);
-                    else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_cols_kernel<2, 8, OUT>", (vpp_area_cols_kernel<2, 8, OUT>), grid, cblock, 0);
-                    else TSVPP_LAUNCH("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
+                    if (d.nkx == 1) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<1, 8, OUT>", (vpp_area_cols_kernel<1, 8, OUT>), grid, cblock, 0);
+                    else if (d.nkx == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<2, 8, OUT>", (vpp_area_cols_kernel<2, 8, OUT>), grid, cblock, 0);
+                    else TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_cols_kernel<3, 8, OUT>", (vpp_area_cols_kernel<3, 8, OUT>), grid, cblock, 0);
                 }
                 return info ? hipSuccess : hipGetLastError();
             }
             if (vec && d.area_direct == 2 && !d.force_gather) { // large non-dyadic ratios: float sums straight from global memory
-                if (d.nkx == 1) TSVPP_LAUNCH("vpp_area_direct_float_kernel<1, OUT>", (vpp_area_direct_float_kernel<1, OUT>), grid, block, 0);
-                else if (d.nkx == 2) TSVPP_LAUNCH("vpp_area_direct_float_kernel<2, OUT>", (vpp_area_direct_float_kernel<2, OUT>), grid, block, 0);
-                else TSVPP_LAUNCH("vpp_area_direct_float_kernel<3, OUT>", (vpp_area_direct_float_kernel<3, OUT>), grid, block, 0);
+                if (d.nkx == 1) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_direct_float_kernel<1, OUT>", (vpp_area_direct_float_kernel<1, OUT>), grid, block, 0);
+                else if (d.nkx == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_direct_float_kernel<2, OUT>", (vpp_area_direct_float_kernel<2, OUT>), grid, block, 0);
+                else TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_direct_float_kernel<3, OUT>", (vpp_area_direct_float_kernel<3, OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
             if (staged && d.qx && d.qy) {
                 if (d.rx <= 4) {
-                    if (d.ry == 2) TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 2, OUT>", (vpp_area_dyadic_kernel<1, 2, OUT>), grid, block, lds_bytes);
-                    else if (d.ry == 3) TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 3, OUT>", (vpp_area_dyadic_kernel<1, 3, OUT>), grid, block, lds_bytes);
-                    else TSVPP_LAUNCH("vpp_area_dyadic_kernel<1, 0, OUT>", (vpp_area_dyadic_kernel<1, 0, OUT>), grid, block, lds_bytes);
+                    if (d.ry == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_dyadic_kernel<1, 2, OUT>", (vpp_area_dyadic_kernel<1, 2, OUT>), grid, block, lds_bytes);
+                    else if (d.ry == 3) TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_dyadic_kernel<1, 3, OUT>", (vpp_area_dyadic_kernel<1, 3, OUT>), grid, block, lds_bytes);
+                    else TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_dyadic_kernel<1, 0, OUT>", (vpp_area_dyadic_kernel<1, 0, OUT>), grid, block, lds_bytes);
                 } else {
-                    TSVPP_LAUNCH("vpp_area_dyadic_kernel<2, 0, OUT>", (vpp_area_dyadic_kernel<2, 0, OUT>), grid, block, lds_bytes);
+                    TSVPP_LAUNCH_OR_DESCRIBE("vpp_area_dyadic_kernel<2, 0, OUT>", (vpp_area_dyadic_kernel<2, 0, OUT>), grid, block, lds_bytes);
                 }
                 return info ? hipSuccess : hipGetLastError();
             }
         }
         if constexpr (MODE == M_AREA_DOWN) {
             if (staged && d.area2) { // float weights, at most 3 x 3 taps
-                if (d.rx == 2 && d.ry == 2) TSVPP_LAUNCH("vpp_areaf_kernel<2, 2, OUT>", (vpp_areaf_kernel<2, 2, OUT>), grid, block, lds_bytes);
-                else if (d.rx == 3 && d.ry == 2) TSVPP_LAUNCH("vpp_areaf_kernel<3, 2, OUT>", (vpp_areaf_kernel<3, 2, OUT>), grid, block, lds_bytes);
-                else if (d.rx == 2 && d.ry == 3) TSVPP_LAUNCH("vpp_areaf_kernel<2, 3, OUT>", (vpp_areaf_kernel<2, 3, OUT>), grid, block, lds_bytes);
-                else TSVPP_LAUNCH("vpp_areaf_kernel<3, 3, OUT>", (vpp_areaf_kernel<3, 3, OUT>), grid, block, lds_bytes);
+                if (d.rx == 2 && d.ry == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_areaf_kernel<2, 2, OUT>", (vpp_areaf_kernel<2, 2, OUT>), grid, block, lds_bytes);
+                else if (d.rx == 3 && d.ry == 2) TSVPP_LAUNCH_OR_DESCRIBE("vpp_areaf_kernel<3, 2, OUT>", (vpp_areaf_kernel<3, 2, OUT>), grid, block, lds_bytes);
+                else if (d.rx == 2 && d.ry == 3) TSVPP_LAUNCH_OR_DESCRIBE("vpp_areaf_kernel<2, 3, OUT>", (vpp_areaf_kernel<2, 3, OUT>), grid, block, lds_bytes);
+                else TSVPP_LAUNCH_OR_DESCRIBE("vpp_areaf_kernel<3, 3, OUT>", (vpp_areaf_kernel<3, 3, OUT>), grid, block, lds_bytes);
                 return info ? hipSuccess : hipGetLastError();
             }
         }
     } else {
         if constexpr (OUT == O_Y800_U8 || OUT == O_NV12_U8) {
             if (staged && d.copy16) {
-                TSVPP_LAUNCH("vpp_copy16_kernel<OUT>", (vpp_copy16_kernel<OUT>), grid, block, 0);
+                TSVPP_LAUNCH_OR_DESCRIBE("vpp_copy16_kernel<OUT>", (vpp_copy16_kernel<OUT>), grid, block, 0);
                 return info ? hipSuccess : hipGetLastError();
             }
         }
         if (staged) { // colour-only fast path ("staged" = eligible)
-            TSVPP_LAUNCH("vpp_color_kernel<OUT>", (vpp_color_kernel<OUT>), grid, block, 0);
+            TSVPP_LAUNCH_OR_DESCRIBE("vpp_color_kernel<OUT>", (vpp_color_kernel<OUT>), grid, block, 0);
             return info ? hipSuccess : hipGetLastError();
         }
     }
     if (vec)
-        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
+        TSVPP_LAUNCH_OR_DESCRIBE("vpp_fused_gather_kernel<MODE, OUT, true>", (vpp_fused_gather_kernel<MODE, OUT, true>), grid, block, 0);
     else // outputs that are not 16-byte aligned: element-wise stores
-        TSVPP_LAUNCH("vpp_fused_gather_kernel<MODE, OUT, false>", (vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0);
+        TSVPP_LAUNCH_OR_DESCRIBE("vpp_fused_gather_kernel<MODE, OUT, false>", (vpp_fused_gather_kernel<MODE, OUT, false>), grid, block, 0);
     return info ? hipSuccess : hipGetLastError();
 }
 

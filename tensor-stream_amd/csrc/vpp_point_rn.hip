@@ -152,7 +152,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_rep2_kernel(const LaunchDesc 
 template <int N, int OFF>
 static hipError_t launch_prn(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
-#define TSVPP_PRN(O) case O: hipLaunchKernelGGL((vpp_point_rn_kernel<O, N, OFF>), grid, block, 0, stream, d, t); break;
+#define TSVPP_PRN(O) case O: TSVPP_LAUNCH((vpp_point_rn_kernel<O, N, OFF>), grid, block, 0, stream, d, t); break;
         TSVPP_PRN(O_U8_PLANAR) TSVPP_PRN(O_U8_MERGED) TSVPP_PRN(O_NV12_U8) TSVPP_PRN(O_Y800_U8)
         TSVPP_PRN(O_F32_PLANAR) TSVPP_PRN(O_F32_MERGED) TSVPP_PRN(O_NV12_F32) TSVPP_PRN(O_Y800_F32) TSVPP_PRN(O_HSV_F32)
 #undef TSVPP_PRN
@@ -173,7 +173,7 @@ hipError_t launch_point_rn(OutKind out, const LaunchDesc &d, const FrameTable &t
             return hipSuccess;
         }
         switch (out) {
-#define TSVPP_REP2(O) case O: hipLaunchKernelGGL((vpp_rep2_kernel<O>), grid, block, 0, stream, d, t); break;
+#define TSVPP_REP2(O) case O: TSVPP_LAUNCH((vpp_rep2_kernel<O>), grid, block, 0, stream, d, t); break;
             TSVPP_REP2(O_U8_PLANAR) TSVPP_REP2(O_U8_MERGED) TSVPP_REP2(O_NV12_U8) TSVPP_REP2(O_Y800_U8)
             TSVPP_REP2(O_F32_PLANAR) TSVPP_REP2(O_F32_MERGED) TSVPP_REP2(O_NV12_F32) TSVPP_REP2(O_Y800_F32) TSVPP_REP2(O_HSV_F32)
 #undef TSVPP_REP2

@@ -9,6 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "lib", "libtsvpp.so"))
 
 TSVPP_MAX_BATCH = 128
+TSVPP_OPT_INPUTS_READY = 1
 
 
 class NV12(ctypes.Structure):
@@ -36,7 +37,7 @@ class Coeffs(ctypes.Structure):
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
            "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs",
            "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version",
-           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table", "tsvpp_trim"]
+           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table", "tsvpp_trim", "tsvpp_set_option", "tsvpp_get_option"]
 
 _lib = None
 
@@ -70,6 +71,10 @@ def lib():
     L.tsvpp_convert_table.argtypes = [vp, vp, i32, i32, pp, vp]
     L.tsvpp_trim.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
     L.tsvpp_trim.restype = i32
+    L.tsvpp_set_option.argtypes = [vp, i32, i32]
+    L.tsvpp_set_option.restype = i32
+    L.tsvpp_get_option.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.tsvpp_get_option.restype = i32
     L.tsvpp_prepare.argtypes = [vp, pp, i32, i32]
     L.tsvpp_prepare_batch.argtypes = [vp, pp, i32, i32, i32, vp]
     L.tsvpp_enable_markers.argtypes = [vp, i32]
