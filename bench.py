@@ -278,16 +278,19 @@ def curve_frame(frame_id, pitch, src_h):
 
 CURVE_NS = (1, 2, 4, 8, 16, 32, 64)
 # consumer shapes of the launch curve: threads x streams per thread (vpp_curve.cpp) -> key in the line
-CURVE_MODES = (("1x1", "one_consumer"), ("4x1", "four_consumers"))
+CURVE_MODES = (("1xc", "one_consumer"), ("4xc", "four_consumers"))  # "c": through the context's consumer pool (tsvpp_consumer_next_stream), as VideoProcessor::ConvertInto
 
 
 def launch_curve_leg(names=("headline", "c3", "c4"), ns=CURVE_NS, modes=CURVE_MODES, target_ms=30.0, inputs_ready=(0, 1), parity=True):
     """the hot path at the launch sizes the reference's calling pattern produces -- ONE frame per Convert (reference
     src/Wrappers/WrapperPython.cpp:265-363) out of a ring of 5-10 frames (include/Decoder.h:19) -- i.e. 1 .. 64 frames per launch, on rotating pools whose moved bytes
     exceed 640 MiB per issuing thread (tensor-stream_amd/cpp/vpp_curve.cpp, its own process, after the timed region).  Per workload and n:
-      one_consumer     every launch on ONE stream, back to back (HIP events on that stream; the dependent-launch boundary is inside the figure);
-      four_consumers   four host threads, each with its own stream (the reference's model: one stream per consumer name), wall clock over all launches;
-      *_inputs_ready   the same with TSVPP_OPT_INPUTS_READY (include/tsvpp.h): launches do not wait for their predecessors on the stream.
+      one_consumer     one named consumer of the context, every launch on its stream (tsvpp_consumer_next_stream, as VideoProcessor::ConvertInto), back to back:
+                       the dependent-launch boundary is inside the figure;
+      four_consumers   four host threads, each a named consumer with its own stream (the reference's model: one stream per consumer name);
+      *_inputs_ready   the same with TSVPP_OPT_INPUTS_READY (include/tsvpp.h): a consumer alternates between two streams and its launches do not wait for their
+                       predecessors -- legal for the reference's hand-off (the decoder has finished the frame before getFrame returns it).
+    Wall clock from a common start until every stream is synchronised, median of five regions of ~30 ms.
     `frac` = moved bytes per launch / time per launch / 8 TB/s; moved bytes = the ROI formula, or for the sparse samplers (C3, C4) the PMC traffic per frame of the
     profiled launch when that entry is fresh, else the touched bytes (a lower bound).  Every point is checked against the oracle: CRC-32 of the first and the last
     output frame of the last launch (the pool's outputs are overwritten before every point)."""
@@ -326,8 +329,8 @@ def launch_curve_leg(names=("headline", "c3", "c4"), ns=CURVE_NS, modes=CURVE_MO
             out = json.loads(lines[-1])
             entry["pool_frames_per_thread"] = out["pool_frames_per_thread"]
             for mode, key in modes:
-                t, st = (int(x) for x in mode.split("x"))
-                pts = [q for q in out["points"] if q["threads"] == t and q["streams_per_thread"] == st]
+                t, st = mode.split("x")
+                pts = [q for q in out["points"] if q["threads"] == int(t) and ((st == "c" and q.get("consumer_pool")) or (st != "c" and not q.get("consumer_pool") and q["streams_per_thread"] == int(st)))]
                 pts.sort(key=lambda q: q["n"])
                 k = key + ("_inputs_ready" if ready else "")
                 entry[k] = {"us_per_launch": [round(q["us_per_launch"], 3) for q in pts],

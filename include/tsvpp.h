@@ -104,6 +104,14 @@ void tsvpp_destroy(tsvpp_ctx *ctx);
  * src/VideoProcessor.cpp:98-104): the stream bound to `name`, claiming a free slot
  * for a new name; TSVPP_ERROR when all `max_consumers` slots are taken. */
 int tsvpp_consumer_stream(tsvpp_ctx *ctx, const char *name, void **out_stream);
+/* The stream the consumer's NEXT conversion should be enqueued on (round 6; VideoProcessor::Convert / ConvertInto use it).  By default that is
+ * tsvpp_consumer_stream's: one stream per consumer, every conversion ordered behind the previous one -- the reference's model.  Under
+ * TSVPP_OPT_INPUTS_READY (below) a consumer owns TWO streams and this call alternates between them: conversion k + 1 is launched while conversion k still
+ * drains (a single 1080p -> 720p frame is ~2.3 us of HBM time behind a ~1.5-1.9 us dependent-launch boundary; measured: one consumer, one frame per launch,
+ * 0.28 -> 0.42 of the HBM roofline, two frames per launch 0.46 -> 0.69; profiles/r06_curve_*.txt).  The second stream is created on the consumer's first call
+ * with the option set (one hipStreamCreate).  tsvpp_consumer_synchronize waits (on the host) for everything enqueued on the consumer's streams. */
+int tsvpp_consumer_next_stream(tsvpp_ctx *ctx, const char *name, void **out_stream);
+int tsvpp_consumer_synchronize(tsvpp_ctx *ctx, const char *name);
 
 /* Stage selection of Convert() (reference src/VideoProcessor.cpp:106-135) without
  * running anything: final width/height and the tight output size in bytes. */
@@ -178,6 +186,7 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on);
  * carry nothing but conversions (src/VideoProcessor.cpp:98-104).  A pipeline with that shape may set this option: every fused launch of the context then goes
  * out with the AQL barrier bit cleared (hipExtAnyOrderLaunch) -- it does not wait for work enqueued EARLIER on its stream, so back-to-back single-frame
  * conversions of one consumer overlap instead of paying a dependent-launch boundary each (~1.5-1.9 us against ~2.3 us of HBM time for a 1080p -> 720p frame).
+ * Consumers served through tsvpp_consumer_next_stream additionally alternate between two streams (see there).
  * The caller promises, for every conversion while the option is set:
  *   (1) the input planes are complete in device memory when the call is made (not merely enqueued earlier on `stream`);
  *   (2) nothing enqueued earlier on `stream` still reads or writes the output buffer.

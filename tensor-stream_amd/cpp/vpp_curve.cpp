@@ -6,13 +6,16 @@
 // pool of distinct frames whose moved bytes exceed 640 MiB per issuing thread (the Infinity Cache holds 256 MiB: every launch reads and writes HBM), in two shapes:
 //   TxS = 1x1   one consumer: every launch on ONE stream, back to back (each waits for its predecessor: the dependent-launch boundary is inside the figure);
 //   TxS = T x S T host threads, each with S streams of its own, issuing round-robin (the reference's concurrency model: one stream per consumer name, one host
-//               thread per consumer) -- launches of different streams overlap, the figure is wall time over all launches.
+//               thread per consumer) -- launches of different streams overlap, the figure is wall time over all launches;
+//   Txc         T host threads, each a NAMED CONSUMER of the context: every launch goes to tsvpp_consumer_next_stream(name) -- what VideoProcessor::ConvertInto
+//               does.  Without TSVPP_OPT_INPUTS_READY that is the consumer's one stream (== Tx1 on the pool's blocking streams); with it (last argument 1) the
+//               consumer alternates between its two streams and the launches carry no barrier bit.
 // Every point ends with the CRC-32 (zlib polynomial) of the first and the last output frame of thread 0's LAST launch; the whole output pool is overwritten with 0xCD
 // before the point, so a CRC can only match the oracle's if this point's launches wrote the frame.  Inputs are a counter hash (lowbias32) that bench.py
 // regenerates on the host for the oracle.  Prints ONE JSON line.
 //
 // usage: vpp_curve W H pitch cl ct cr cb dstW dstH resizeType fourcc planes norm movedBytesPerFrame nList modeList [target_ms [any_order]]
-//        nList "1,2,4,8"; modeList "1x1,4x1" (threads x streams per thread)
+//        nList "1,2,4,8"; modeList "1x1,4x1,1xc" (threads x streams per thread; c = through the consumer pool); movedBytesPerFrame sizes the pool (see main)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -99,11 +102,12 @@ int main(int argc, char **argv) {
     const double moved = atof(argv[14]);
     std::vector<int> ns;
     for (auto &s : split(argv[15], ',')) ns.push_back(atoi(s.c_str()));
-    std::vector<std::pair<int, int>> modes;
+    std::vector<std::pair<int, int>> modes; // (threads, streams per thread; 0 = through the consumer pool)
     for (auto &s : split(argv[16], ',')) {
         int t = 1, st = 1;
-        sscanf(s.c_str(), "%dx%d", &t, &st);
-        modes.emplace_back(std::max(1, t), std::max(1, st));
+        if (s.find('c') != std::string::npos) { sscanf(s.c_str(), "%dx", &t); st = 0; }
+        else sscanf(s.c_str(), "%dx%d", &t, &st);
+        modes.emplace_back(std::max(1, t), std::max(0, st));
     }
     const double target_ms = argc > 17 ? atof(argv[17]) : 30.0;
     const int any_order = argc > 18 ? atoi(argv[18]) : 0;
@@ -114,7 +118,7 @@ int main(int argc, char **argv) {
     crc_init();
 
     tsvpp_ctx *ctx = nullptr;
-    if (tsvpp_create(0, 0, &ctx) != 0) return 4;
+    if (tsvpp_create(0, max_t, &ctx) != 0) return 4;
 #ifdef TSVPP_HAVE_OPTIONS
     if (any_order && tsvpp_set_option(ctx, TSVPP_OPT_INPUTS_READY, 1) != 0) return 4;
 #else
@@ -124,10 +128,13 @@ int main(int argc, char **argv) {
     if (!out_bytes) { fprintf(stderr, "vpp_curve: unsupported request\n"); return 5; }
     const size_t out_stride = (out_bytes + 255) & ~(size_t)255;
     const size_t y_bytes = (size_t)pitch * H, in_stride = y_bytes * 3 / 2;
-    // frames per thread: their MOVED bytes exceed 640 MiB, a multiple of the largest launch (and of 64)
-    int per_thread = (int)((640.0 * 1048576.0) / (moved > 0 ? moved : 1.0)) + 1;
+    // Frames per issuing thread: the bytes a pass over the pool READS exceed 768 MiB (three times the 256 MiB Infinity Cache: a cyclic sweep then finds nothing of
+    // its previous pass -- the first version of this driver sized the pool by moved bytes alone, 64 headline frames, whose 212 MB of inputs stayed cache-resident
+    // and flattered the large launches: 0.90 "of the roofline" at n = 64) and the bytes it moves exceed 2 GiB; a multiple of 64, at most 1024.
+    const double read_est = std::max(moved - (double)out_bytes, 1.0);
+    int per_thread = (int)std::max((768.0 * 1048576.0) / read_est, (2048.0 * 1048576.0) / (moved > 0 ? moved : 1.0)) + 1;
     const int gran = std::max(64, max_n);
-    per_thread = (per_thread + gran - 1) / gran * gran;
+    per_thread = std::min(1024, (per_thread + gran - 1) / gran * gran);
 
     std::vector<Slice> pool((size_t)max_t);
     for (int t = 0; t < max_t; t++) {
@@ -143,7 +150,7 @@ int main(int argc, char **argv) {
             s.desc.push_back(tsvpp_nv12{ y, y + y_bytes, pitch, pitch, W, H });
             s.outs.push_back(s.out + (size_t)f * out_stride);
         }
-        for (int k = 0; k < max_s; k++) {
+        for (int k = 0; k < std::max(1, max_s); k++) {
             hipStream_t st = nullptr;
             CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             s.streams.push_back(st);
@@ -156,15 +163,31 @@ int main(int argc, char **argv) {
     bool first_point = true;
     std::vector<uint8_t> host(out_bytes);
     for (auto &mode : modes) {
-        const int T = mode.first, S = mode.second;
+        const int T = mode.first, S = std::max(1, mode.second);
+        const bool pool_mode = mode.second == 0;
         for (int n : ns) {
             if (tsvpp_prepare_batch(ctx, &p, W, H, n, nullptr) != 0) return 6;
             for (int t = 0; t < max_t; t++) CK(hipMemsetAsync(pool[(size_t)t].out, 0xCD, out_stride * per_thread, nullptr));
             CK(hipDeviceSynchronize());
             // launch i of a thread converts its frames [(i n) mod F, +n) on its stream i mod S
-            auto issue = [&](Slice &s, long i) {
+            auto issue = [&](Slice &s, long i, int t = 0) {
                 const int base = (int)((i * (long)n) % s.frames);
-                return tsvpp_convert_batch(ctx, n, s.desc.data() + base, &p, s.outs.data() + base, s.streams[(size_t)(i % S)]);
+                void *st = s.streams[(size_t)(i % S)];
+                if (pool_mode) {
+                    char name[16];
+                    snprintf(name, sizeof(name), "c%d", t);
+                    if (tsvpp_consumer_next_stream(ctx, name, &st) != 0) return -1;
+                }
+                return tsvpp_convert_batch(ctx, n, s.desc.data() + base, &p, s.outs.data() + base, st);
+            };
+            auto sync_thread = [&](Slice &s, int t) {
+                if (pool_mode) {
+                    char name[16];
+                    snprintf(name, sizeof(name), "c%d", t);
+                    (void)tsvpp_consumer_synchronize(ctx, name);
+                    return;
+                }
+                for (int q = 0; q < S; q++) (void)hipStreamSynchronize(s.streams[(size_t)q]);
             };
             // calibration + warm-up on thread 0's slice: ~25 ms of work settles the clocks
             long done0 = 0;
@@ -175,7 +198,7 @@ int main(int argc, char **argv) {
                 while (now_us() - t0 < 25e3) {
                     for (int j = 0; j < 16; j++)
                         if (issue(pool[0], k++) != 0) return 7;
-                    for (int q = 0; q < S; q++) CK(hipStreamSynchronize(pool[0].streams[(size_t)q]));
+                    sync_thread(pool[0], 0);
                 }
                 per_launch_us = (now_us() - t0) / (double)k;
                 done0 = k;
@@ -193,7 +216,7 @@ int main(int argc, char **argv) {
                 std::vector<int> err((size_t)T, 0);
                 float ev_ms = 0.0f;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (T == 1 && S == 1) {
+                if (T == 1 && S == 1 && !pool_mode) {
                     CK(hipEventCreate(&e0));
                     CK(hipEventCreate(&e1));
                 }
@@ -206,10 +229,10 @@ int main(int argc, char **argv) {
                     if (e0) (void)hipEventRecord(e0, s.streams[0]);
                     const long i0 = done0 + (long)r * K;
                     for (long i = 0; i < K; i++)
-                        if (issue(s, i0 + i) != 0) { err[(size_t)t] = 1; break; }
+                        if (issue(s, i0 + i, t) != 0) { err[(size_t)t] = 1; break; }
                     if (e1) (void)hipEventRecord(e1, s.streams[0]);
                     t_host[(size_t)t] = now_us() - h0;
-                    for (int q = 0; q < S; q++) (void)hipStreamSynchronize(s.streams[(size_t)q]);
+                    sync_thread(s, t);
                     t_end[(size_t)t] = now_us();
                 };
                 std::vector<std::thread> th;
@@ -245,10 +268,10 @@ int main(int argc, char **argv) {
                 CK(hipMemcpy(host.data(), pool[0].outs[(size_t)chk[c]], out_bytes, hipMemcpyDeviceToHost));
                 crc[c] = crc32_of(host.data(), out_bytes);
             }
-            printf("%s{\"n\": %d, \"threads\": %d, \"streams_per_thread\": %d, \"launches_per_thread\": %ld, \"us_per_launch\": %.3f, \"us_per_launch_reps\": [%.3f, %.3f, %.3f, %.3f, %.3f], "
+            printf("%s{\"n\": %d, \"threads\": %d, \"streams_per_thread\": %d, \"consumer_pool\": %d, \"launches_per_thread\": %ld, \"us_per_launch\": %.3f, \"us_per_launch_reps\": [%.3f, %.3f, %.3f, %.3f, %.3f], "
                    "\"host_issue_us_per_launch\": %.3f, \"timer\": \"%s\", \"check\": [{\"frame\": %d, \"crc32\": %u}, {\"frame\": %d, \"crc32\": %u}]}",
-                   first_point ? "" : ", ", n, T, S, K, med, reps_us[0], reps_us[1], reps_us[2], reps_us[3], reps_us[4], host_us[host_us.size() / 2],
-                   (T == 1 && S == 1) ? "hip events on the launch stream" : "wall clock, start barrier -> every stream synchronised", chk[0], crc[0], chk[1], crc[1]);
+                   first_point ? "" : ", ", n, T, pool_mode ? 0 : S, pool_mode ? 1 : 0, K, med, reps_us[0], reps_us[1], reps_us[2], reps_us[3], reps_us[4], host_us[host_us.size() / 2],
+                   (T == 1 && S == 1 && !pool_mode) ? "hip events on the launch stream" : "wall clock, start barrier -> every stream synchronised", chk[0], crc[0], chk[1], crc[1]);
             first_point = false;
             fflush(stdout);
         }

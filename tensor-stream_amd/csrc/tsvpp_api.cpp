@@ -217,6 +217,8 @@ struct Plan {
 struct tsvpp_ctx {
     int device = 0;
     std::vector<std::pair<std::string, hipStream_t>> streams;
+    std::vector<hipStream_t> streams2; // TSVPP_OPT_INPUTS_READY: a consumer's second stream (created on first use), same index as `streams`
+    std::vector<uint8_t> turn;         // ... and which of the two its next conversion takes
     std::mutex stream_mu;
     tsvpp_coeffs coeffs;
     std::map<uint32_t, AreaTable> area; // keyed by the bit pattern of the float scale
@@ -666,6 +668,8 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
         }
         ctx->streams.emplace_back(std::string("empty"), s);
     }
+    ctx->streams2.assign(ctx->streams.size(), nullptr);
+    ctx->turn.assign(ctx->streams.size(), 0);
     *out_ctx = ctx;
     return TSVPP_OK;
 }
@@ -676,6 +680,8 @@ void tsvpp_destroy(tsvpp_ctx *ctx) {
         DeviceGuard guard(ctx);
         for (auto &s : ctx->streams)
             if (s.second) (void)hipStreamDestroy(s.second);
+        for (hipStream_t s : ctx->streams2)
+            if (s) (void)hipStreamDestroy(s);
         for (auto &sc : ctx->scratch)
             if (sc.second && sc.second->buf) (void)hipFree(sc.second->buf);
         for (uint8_t *b : ctx->retired) (void)hipFree(b);
@@ -708,6 +714,62 @@ int tsvpp_consumer_stream(tsvpp_ctx *ctx, const char *name, void **out_stream) {
     }
     *out_stream = nullptr;
     return TSVPP_ERROR; // pool exhausted (reference src/VideoProcessor.cpp:100-103)
+}
+
+// Index of the consumer's pool slot (claiming a free one for a new name), or -1 (caller holds stream_mu).
+static int consumer_slot(tsvpp_ctx *ctx, const char *name) {
+    for (size_t i = 0; i < ctx->streams.size(); i++) {
+        auto &s = ctx->streams[i];
+        if (s.first == name) return (int)i;
+        if (s.first == "empty") {
+            s.first = name;
+            return (int)i;
+        }
+    }
+    return -1;
+}
+
+int tsvpp_consumer_next_stream(tsvpp_ctx *ctx, const char *name, void **out_stream) {
+    if (!ctx || !name || !out_stream) return TSVPP_ERROR;
+    *out_stream = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->stream_mu);
+    const int i = consumer_slot(ctx, name);
+    if (i < 0) return TSVPP_ERROR; // pool exhausted (reference src/VideoProcessor.cpp:100-103)
+    if (!ctx->inputs_ready) {
+        *out_stream = (void *)ctx->streams[(size_t)i].second;
+        return TSVPP_OK;
+    }
+    if (!ctx->streams2[(size_t)i]) {
+        DeviceGuard guard(ctx);
+        if (guard.status != TSVPP_OK) return guard.status;
+        hipStream_t s = nullptr;
+        const hipError_t e = hipStreamCreate(&s); // blocking, as the pool's first stream
+        if (e != hipSuccess) return (int)e;
+        ctx->streams2[(size_t)i] = s;
+    }
+    const uint8_t t = ctx->turn[(size_t)i];
+    ctx->turn[(size_t)i] = t ^ 1;
+    *out_stream = (void *)(t ? ctx->streams2[(size_t)i] : ctx->streams[(size_t)i].second);
+    return TSVPP_OK;
+}
+
+int tsvpp_consumer_synchronize(tsvpp_ctx *ctx, const char *name) {
+    if (!ctx || !name) return TSVPP_ERROR;
+    hipStream_t a = nullptr, b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->stream_mu);
+        int i = -1;
+        for (size_t k = 0; k < ctx->streams.size(); k++)
+            if (ctx->streams[k].first == name) i = (int)k;
+        if (i < 0) return TSVPP_ERROR; // no such consumer
+        a = ctx->streams[(size_t)i].second;
+        b = ctx->streams2[(size_t)i];
+    }
+    DeviceGuard guard(ctx);
+    if (guard.status != TSVPP_OK) return guard.status;
+    hipError_t e = hipStreamSynchronize(a);
+    if (e == hipSuccess && b) e = hipStreamSynchronize(b);
+    return (int)e;
 }
 
 float tsvpp_channels(int fourcc) {

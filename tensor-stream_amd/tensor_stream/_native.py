@@ -37,7 +37,7 @@ class Coeffs(ctypes.Structure):
 SYMBOLS = ["tsvpp_create", "tsvpp_destroy", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_out_bytes",
            "tsvpp_channels", "tsvpp_convert", "tsvpp_convert_batch", "tsvpp_prepare", "tsvpp_prepare_batch", "tsvpp_enable_markers", "tsvpp_get_coeffs",
            "tsvpp_set_coeffs", "tsvpp_default_coeffs", "tsvpp_area_pattern", "tsvpp_describe", "tsvpp_strerror", "tsvpp_version",
-           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table", "tsvpp_trim", "tsvpp_set_option", "tsvpp_get_option"]
+           "tsvpp_table_create", "tsvpp_table_destroy", "tsvpp_table_set", "tsvpp_convert_table", "tsvpp_trim", "tsvpp_set_option", "tsvpp_get_option", "tsvpp_consumer_next_stream", "tsvpp_consumer_synchronize"]
 
 _lib = None
 
@@ -57,6 +57,10 @@ def lib():
     L.tsvpp_destroy.argtypes = [vp]
     L.tsvpp_destroy.restype = None
     L.tsvpp_consumer_stream.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.tsvpp_consumer_next_stream.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.tsvpp_consumer_next_stream.restype = i32
+    L.tsvpp_consumer_synchronize.argtypes = [vp, ctypes.c_char_p]
+    L.tsvpp_consumer_synchronize.restype = i32
     L.tsvpp_out_dims.argtypes = [pp, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.tsvpp_out_bytes.argtypes = [pp, i32, i32]
     L.tsvpp_out_bytes.restype = ctypes.c_size_t

@@ -165,7 +165,7 @@ def test_cpp_host_library_links_against_the_abi(native):
         g.build()
     out = subprocess.run(["nm", "-D", "--undefined-only", host], capture_output=True, text=True).stdout
     used = set(re.findall(r"\b(tsvpp_[a-z0-9_]+)", out))
-    assert {"tsvpp_create", "tsvpp_convert", "tsvpp_consumer_stream", "tsvpp_out_dims", "tsvpp_destroy"} <= used
+    assert {"tsvpp_create", "tsvpp_convert", "tsvpp_consumer_next_stream", "tsvpp_out_dims", "tsvpp_destroy"} <= used
     assert used <= set(native.SYMBOLS)
     defined = subprocess.run(["nm", "-D", "--defined-only", host], capture_output=True, text=True).stdout
     assert "VideoProcessor7Convert" in defined and "VideoProcessor4Init" in defined and "channelsByFourCC" in defined
