@@ -162,8 +162,8 @@ int VideoProcessor::Init(std::shared_ptr<Logger> log, uint8_t maxConsumers, bool
 int VideoProcessor::ConvertInto(AVFrame *input, void *deviceOut, FrameParameters &options, std::string consumerName, int *outW, int *outH) {
     if (isClosed || !input || !deviceOut) CHECK_STATUS(VREADER_ERROR);
     void *stream = nullptr;
-    // the consumer's stream -- or, under TSVPP_OPT_INPUTS_READY, the one of its two streams whose turn it is (include/tsvpp.h)
-    CHECK_STATUS(tsvpp_consumer_next_stream(ctx, consumerName.c_str(), &stream)); // pool exhausted -> VREADER_ERROR
+    // the consumer's stream -- or, under TSVPP_OPT_INPUTS_READY, the one of its two streams whose turn it is (include/tsvpp.h; one frame: always "small")
+    CHECK_STATUS(tsvpp_consumer_next_stream(ctx, consumerName.c_str(), 0, &stream)); // pool exhausted -> VREADER_ERROR
     const tsvpp_nv12 in{ input->data[0], input->data[1], input->linesize[0], input->linesize[1], input->width, input->height };
     const tsvpp_params p = flatten(options);
     int w = 0, h = 0;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -271,7 +272,16 @@ struct tsvpp_ctx {
     std::mutex scratch_mu;
     int markers = 0; // tsvpp_enable_markers: roctx ranges around every conversion (the reference's NVTX ranges)
     int inputs_ready = 0; // TSVPP_OPT_INPUTS_READY: fused launches do not wait for earlier work on their stream (include/tsvpp.h)
+    // Replay cache (convert_impl): a thread keeps the finished launches of its last requests, keyed by this context's id and epoch.  The epoch moves whenever
+    // something a finished launch descriptor depends on changes or may be freed: tsvpp_set_coeffs, tsvpp_set_option, tsvpp_enable_markers, tsvpp_trim.
+    uint64_t id = 0;
+    std::atomic<uint64_t> epoch{ 1 };
+    int replay = 1; // TSVPP_REPLAY=0 (debug knob): every call runs the full selection
 };
+
+namespace tsvpp {
+thread_local LaunchRecord *g_launch_rec = nullptr;
+}
 
 namespace {
 
@@ -376,6 +386,7 @@ void read_env_knobs(tsvpp_ctx *ctx) {
     if (const char *e = std::getenv("TSVPP_AREA_COLS_ROWS")) ctx->area_cols_rows = std::atoi(e); // 8 | 32: tile height of the column-per-lane AREA kernel (default: by tap count and launch size)
     if (const char *e = std::getenv("TSVPP_TILE_ORDER")) ctx->tile_order = std::atoi(e);
     if (const char *e = std::getenv("TSVPP_SHAPE")) std::sscanf(e, "%d,%d", &ctx->shape_tx, &ctx->shape_ty);
+    if (const char *e = std::getenv("TSVPP_REPLAY")) ctx->replay = std::atoi(e);
 }
 
 // The part of the launch descriptor that depends only on the request and the knobs.
@@ -619,6 +630,94 @@ int scratch_grow(tsvpp_ctx *ctx, tsvpp_ctx::ScratchSlot *slot, size_t need) {
 size_t scratch_frame_bytes(const Plan &pl) { return (((size_t)pl.dst_w * pl.dst_h * 3 / 2) + 255) & ~(size_t)255; }
 bool needs_scratch(const Plan &pl) { return (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && pl.mode != M_NONE; }
 
+// ---- replay of a thread's recent launches (round 6) ---------------------------------------------------------------------------------------------------
+// A conversion of ONE frame is host-bound: ~3.3 us of runtime per launch (tools/launch_cost.hip: 3.5 us with this library's 3.7 KiB kernarg segment, 2.65 with a
+// 16-byte one) plus what this file adds -- make_plan, fill_desc, launch_fused's selection, the table caches' mutexes and map lookups.  The latter is the same work for
+// every frame a consumer converts, so a thread keeps the FINISHED launches (host function, grid, final LaunchDesc) of its last eight requests and replays one when
+// the request, the frame geometry, the alignment class of the pointers, the context and its epoch all match.  Only single-launch requests are kept (no second
+// pass, no row-tail launch, no frame table, at most TSVPP_MAX_BATCH frames); TSVPP_REPLAY=0 disables it (the GPU suite is replayed both ways).
+struct ReplayEntry {
+    uint64_t ctx_id = 0, epoch = 0, stamp = 0;
+    tsvpp_params p = {};
+    int w = 0, h = 0, py = 0, puv = 0, n = 0, aligned4 = 0, vec = 0;
+    size_t y_off = 0, uv_off = 0;
+    LaunchRecord rec;
+};
+constexpr int kReplayEntries = 8;
+constexpr int kReplayMiss = -1000;
+thread_local ReplayEntry g_replay[kReplayEntries];
+thread_local uint64_t g_replay_clock = 0;
+struct RecordArm { // points launch_fused's launches at `rec` for the lifetime of this object
+    explicit RecordArm(LaunchRecord *rec) { g_launch_rec = rec; }
+    ~RecordArm() { g_launch_rec = nullptr; }
+};
+
+int try_replay(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream) {
+    const uint64_t epoch = ctx->epoch.load(std::memory_order_relaxed);
+    const int py = in[0].pitch_y ? in[0].pitch_y : in[0].width, puv = in[0].pitch_uv ? in[0].pitch_uv : in[0].width;
+    int flags_for = -1, aligned4 = 0, vec = 0; // alignment class of THIS call, computed once (every entry of one request has the same crop offsets)
+    for (int k = 0; k < kReplayEntries; k++) {
+        ReplayEntry &e = g_replay[k];
+        if (e.ctx_id != ctx->id || e.epoch != epoch || e.n != n || e.w != in[0].width || e.h != in[0].height || e.py != py || e.puv != puv ||
+            std::memcmp(&e.p, p, sizeof(*p)) != 0)
+            continue;
+        if (flags_for < 0) { // the slow path's per-frame checks, in its order
+            bool a4 = (py % 4 == 0) && (puv % 4 == 0), v = true;
+            for (int f = 0; f < n; f++) {
+                if (!in[f].y || !in[f].uv || !outs[f]) return TSVPP_ERROR;
+                if (in[f].width != in[0].width || in[f].height != in[0].height) return TSVPP_UNSUPPORTED;
+                if ((in[f].pitch_y ? in[f].pitch_y : in[f].width) != py) return TSVPP_UNSUPPORTED;
+                if ((in[f].pitch_uv ? in[f].pitch_uv : in[f].width) != puv) return TSVPP_UNSUPPORTED;
+                a4 = a4 && (((uintptr_t)(in[f].y + e.y_off)) % 4 == 0) && (((uintptr_t)(in[f].uv + e.uv_off)) % 4 == 0);
+                v = v && (((uintptr_t)outs[f] & 15) == 0);
+            }
+            aligned4 = a4 ? 1 : 0;
+            vec = v ? 1 : 0;
+            flags_for = k;
+        }
+        if (e.aligned4 != aligned4 || e.vec != vec) continue;
+        DeviceGuard guard(ctx);
+        if (guard.status != TSVPP_OK) return guard.status;
+        FrameTable t; // (only the first n triples and the three ext / off pairs are read)
+        t.y.ext = nullptr; t.y.off = 0;
+        t.uv.ext = nullptr; t.uv.off = 0;
+        t.out.ext = nullptr; t.out.off = 0;
+        for (int f = 0; f < n; f++) {
+            t.y[f] = in[f].y + e.y_off;
+            t.uv[f] = in[f].uv + e.uv_off;
+            t.out[f] = outs[f];
+        }
+        void *args[2] = { (void *)&e.rec.d, (void *)&t };
+        const hipError_t err = e.rec.d.any_order
+                                   ? hipExtLaunchKernel(e.rec.fn, e.rec.grid, e.rec.block, args, e.rec.lds, (hipStream_t)stream, nullptr, nullptr, hipExtAnyOrderLaunch)
+                                   : hipLaunchKernel(e.rec.fn, e.rec.grid, e.rec.block, args, e.rec.lds, (hipStream_t)stream);
+        e.stamp = ++g_replay_clock;
+        return (int)err;
+    }
+    return kReplayMiss;
+}
+
+void remember_launch(const tsvpp_ctx *ctx, uint64_t epoch, int n, const tsvpp_nv12 *in, const tsvpp_params *p, int py, int puv, bool aligned4, bool vec, size_t y_off,
+                     size_t uv_off, const LaunchRecord &rec) {
+    ReplayEntry *slot = &g_replay[0];
+    for (ReplayEntry &e : g_replay)
+        if (e.stamp < slot->stamp) slot = &e;
+    slot->ctx_id = ctx->id;
+    slot->epoch = epoch;
+    slot->stamp = ++g_replay_clock;
+    slot->p = *p;
+    slot->w = in[0].width;
+    slot->h = in[0].height;
+    slot->py = py;
+    slot->puv = puv;
+    slot->n = n;
+    slot->aligned4 = aligned4 ? 1 : 0;
+    slot->vec = vec ? 1 : 0;
+    slot->y_off = y_off;
+    slot->uv_off = uv_off;
+    slot->rec = rec;
+}
+
 } // namespace
 
 extern "C" {
@@ -643,6 +742,8 @@ int tsvpp_create(int device, int max_consumers, tsvpp_ctx **out_ctx) {
     if (e != hipSuccess) return (int)e;
     if (device < 0 || device >= count) return (int)hipErrorInvalidDevice;
     tsvpp_ctx *ctx = new tsvpp_ctx();
+    static std::atomic<uint64_t> next_id{ 1 };
+    ctx->id = next_id.fetch_add(1);
     ctx->device = device;
     DeviceGuard guard(ctx);
     if (guard.status != TSVPP_OK) {
@@ -729,13 +830,13 @@ static int consumer_slot(tsvpp_ctx *ctx, const char *name) {
     return -1;
 }
 
-int tsvpp_consumer_next_stream(tsvpp_ctx *ctx, const char *name, void **out_stream) {
+int tsvpp_consumer_next_stream(tsvpp_ctx *ctx, const char *name, size_t launch_bytes, void **out_stream) {
     if (!ctx || !name || !out_stream) return TSVPP_ERROR;
     *out_stream = nullptr;
     std::lock_guard<std::mutex> lk(ctx->stream_mu);
     const int i = consumer_slot(ctx, name);
     if (i < 0) return TSVPP_ERROR; // pool exhausted (reference src/VideoProcessor.cpp:100-103)
-    if (!ctx->inputs_ready) {
+    if (!(ctx->inputs_ready == 1 || ctx->inputs_ready == 3) || launch_bytes > TSVPP_OVERLAP_MAX_BYTES) { // (large launches do not overlap: see the header)
         *out_stream = (void *)ctx->streams[(size_t)i].second;
         return TSVPP_OK;
     }
@@ -854,6 +955,7 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on) {
     if (!ctx) return TSVPP_ERROR;
     if (on && !roctx().push) return TSVPP_UNSUPPORTED; // no roctx library on this machine
     ctx->markers = on ? 1 : 0;
+    ctx->epoch.fetch_add(1);
     return TSVPP_OK;
 }
 
@@ -880,6 +982,12 @@ struct TableCols {
 static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp_params *p, void *const *outs, void *stream, const TableCols &tab) {
     if (!ctx || !in || !p || !outs || n < 0) return TSVPP_ERROR;
     if (n == 0) return TSVPP_OK;
+    const bool replayable = ctx->replay && tab.y == nullptr && n <= TSVPP_MAX_BATCH && !ctx->markers;
+    const uint64_t epoch0 = ctx->epoch.load(std::memory_order_relaxed);
+    if (replayable) { // the same request as one of this thread's recent ones: its finished launch again, with this call's frame pointers
+        const int r = try_replay(ctx, n, in, p, outs, stream);
+        if (r != kReplayMiss) return r;
+    }
     Plan pl;
     int sts = make_plan(p, in[0].width, in[0].height, pl);
     if (sts != TSVPP_OK) return sts;
@@ -973,7 +1081,9 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const bool from_table = tab.y != nullptr && !two_pass;
     // TSVPP_OPT_INPUTS_READY: never out of a table (tsvpp_table_set's upload is enqueued on this stream: the launch must wait for it), never for the two-pass
     // formats (pass 1 writes the stream's scratch buffer, which the previous call's pass 2 may still be reading)
-    d.any_order = (ctx->inputs_ready && tab.y == nullptr && !two_pass) ? 1 : 0;
+    // ... and only for launches small enough to gain from running beside their predecessor (TSVPP_OVERLAP_MAX_BYTES)
+    d.any_order = ((ctx->inputs_ready == 1 || ctx->inputs_ready == 2) && tab.y == nullptr && !two_pass &&
+                   (size_t)n * ((size_t)pl.src_w * pl.src_h * 3 / 2 + pl.out_bytes) <= TSVPP_OVERLAP_MAX_BYTES) ? 1 : 0;
     int max_launch = TSVPP_MAX_BATCH;
     if (from_table) {
         const long wg_per_frame = (long)((pl.dst_w + 63) / 64) * ((pl.dst_h + 3) / 4);
@@ -1006,8 +1116,15 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
             for (int f = 0; f < cnt; f++)
                 if (((uintptr_t)outs[base + f] & 15) != 0) vec = false;
         if (!(two_pass && pl.mode == M_NONE)) {
-            hipError_t e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
+            LaunchRecord rec;
+            const bool keep = replayable && !two_pass && n <= max_launch; // one launch group, one pass
+            hipError_t e;
+            {
+                RecordArm arm(keep ? &rec : nullptr);
+                e = launch_fused(pl.mode, out_kind, vec, d, t, (hipStream_t)stream);
+            }
             if (e != hipSuccess) return (int)e;
+            if (keep && rec.count == 1 && rec.fn) remember_launch(ctx, epoch0, n, in, p, pitch_y, pitch_uv, aligned4, vec, y_off, uv_off, rec);
         }
         if (two_pass) {
             int fpy = pitch_y, fpuv = pitch_uv;
@@ -1137,6 +1254,7 @@ int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes) {
     if (!ctx) return TSVPP_ERROR;
     DeviceGuard guard(ctx);
     if (guard.status != TSVPP_OK) return guard.status;
+    ctx->epoch.fetch_add(1); // replay records may hold the addresses of retired table sets
     size_t n = geo_cache_trim(ctx->geo);
     {
         std::lock_guard<std::mutex> lk(ctx->scratch_mu);
@@ -1150,7 +1268,11 @@ int tsvpp_trim(tsvpp_ctx *ctx, size_t *released_bytes) {
 int tsvpp_set_option(tsvpp_ctx *ctx, int option, int value) {
     if (!ctx) return TSVPP_ERROR;
     switch (option) {
-    case TSVPP_OPT_INPUTS_READY: ctx->inputs_ready = value ? 1 : 0; return TSVPP_OK;
+    case TSVPP_OPT_INPUTS_READY:
+        if (value < 0 || value > 3) return TSVPP_ERROR;
+        ctx->inputs_ready = value;
+        ctx->epoch.fetch_add(1);
+        return TSVPP_OK;
     default: return TSVPP_UNSUPPORTED;
     }
 }
@@ -1172,6 +1294,7 @@ int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out) {
 int tsvpp_set_coeffs(tsvpp_ctx *ctx, const tsvpp_coeffs *in) {
     if (!ctx || !in) return TSVPP_ERROR;
     ctx->coeffs = *in;
+    ctx->epoch.fetch_add(1);
     return TSVPP_OK;
 }
 

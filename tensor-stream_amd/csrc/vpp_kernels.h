@@ -173,9 +173,33 @@ struct LaunchDesc {
     GeoCache *geo_cache;
 };
 
+// What the last fused launch of this thread was: tsvpp_api.cpp points `g_launch_rec` at a record while it runs launch_fused and, when exactly ONE kernel was
+// launched, keeps the record -- the host function, the grid and the FINAL descriptor -- so that the next call with the same request replays the launch without
+// re-running the selection (round 6: a single-frame launch is host-bound; the selection, its cache lookups and mutexes are ~0.5 us of ~4).
+struct LaunchRecord {
+    const void *fn = nullptr;
+    dim3 grid, block;
+    uint32_t lds = 0;
+    int count = 0; // launches seen since the record was armed
+    LaunchDesc d;
+};
+extern thread_local LaunchRecord *g_launch_rec;
+inline void record_launch(const void *fn, dim3 grid, dim3 block, size_t lds, const LaunchDesc &d) {
+    LaunchRecord *r = g_launch_rec;
+    if (!r) return;
+    if (r->count++ == 0) {
+        r->fn = fn;
+        r->grid = grid;
+        r->block = block;
+        r->lds = (uint32_t)lds;
+        r->d = d;
+    }
+}
+
 // Every fused-kernel launch goes through this: an ordinary in-order launch, or -- LaunchDesc::any_order -- one whose packet does not wait for its predecessors.
 #define TSVPP_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, D, T)                                                                         \
     do {                                                                                                                             \
+        tsvpp::record_launch(reinterpret_cast<const void *>(KERNEL), GRID, BLOCK, LDS, D);                                           \
         if ((D).any_order) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (uint32_t)(LDS), STREAM, nullptr, nullptr, hipExtAnyOrderLaunch, D, T); \
         else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, D, T);                                                             \
     } while (0)

@@ -57,7 +57,7 @@ def lib():
     L.tsvpp_destroy.argtypes = [vp]
     L.tsvpp_destroy.restype = None
     L.tsvpp_consumer_stream.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
-    L.tsvpp_consumer_next_stream.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.tsvpp_consumer_next_stream.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.tsvpp_consumer_next_stream.restype = i32
     L.tsvpp_consumer_synchronize.argtypes = [vp, ctypes.c_char_p]
     L.tsvpp_consumer_synchronize.restype = i32

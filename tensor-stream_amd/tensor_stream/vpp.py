@@ -12,6 +12,9 @@ import torch
 from . import _native as N
 
 
+OPT_INPUTS_READY = N.TSVPP_OPT_INPUTS_READY
+
+
 class FourCC(Enum):  # reference tensor_stream/tensor_stream.py:48-62
     Y800 = 0
     RGB24 = 1
@@ -128,6 +131,25 @@ class VideoProcessor:
         s = ctypes.c_void_p()
         N.check(self._lib.tsvpp_consumer_stream(self._ctx, name.encode(), ctypes.byref(s)))
         return s.value or 0
+
+    def consumer_next_stream(self, name, launch_bytes=0):
+        """The stream the consumer's next conversion should go to (tsvpp_consumer_next_stream): its one stream by default; under OPT_INPUTS_READY small launches
+        alternate between the consumer's two streams."""
+        s = ctypes.c_void_p()
+        N.check(self._lib.tsvpp_consumer_next_stream(self._ctx, name.encode(), int(launch_bytes), ctypes.byref(s)))
+        return s.value or 0
+
+    def consumer_synchronize(self, name):
+        N.check(self._lib.tsvpp_consumer_synchronize(self._ctx, name.encode()))
+
+    def set_option(self, option, value):
+        """Context options of include/tsvpp.h, e.g. set_option(OPT_INPUTS_READY, 1)."""
+        N.check(self._lib.tsvpp_set_option(self._ctx, int(option), int(value)))
+
+    def get_option(self, option):
+        v = ctypes.c_int(0)
+        N.check(self._lib.tsvpp_get_option(self._ctx, int(option), ctypes.byref(v)))
+        return v.value
 
     def _alloc(self, p, in_w, in_h, n=None):
         ow, oh = self.out_dims(p, in_w, in_h)
