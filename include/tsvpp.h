@@ -108,12 +108,13 @@ int tsvpp_consumer_stream(tsvpp_ctx *ctx, const char *name, void **out_stream);
  * tsvpp_consumer_stream's: one stream per consumer, every conversion ordered behind the previous one -- the reference's model.  Under
  * TSVPP_OPT_INPUTS_READY (below) a consumer owns TWO streams and this call alternates between them: conversion k + 1 is launched while conversion k still
  * drains (a single 1080p -> 720p frame is ~2.3 us of HBM time behind a ~1.5-1.9 us dependent-launch boundary; measured: one consumer, one frame per launch,
- * 0.28 -> 0.42 of the HBM roofline, two frames per launch 0.46 -> 0.69; profiles/r06_curve_*.txt).  `launch_bytes` = the bytes the conversion about to be
+ * 0.27 -> 0.41 of the HBM roofline, two frames per launch 0.44 -> 0.58, four 0.47 -> 0.68, eight 0.60 -> 0.72; profiles/r06_curve_values.txt).  `launch_bytes` = the bytes the conversion about to be
  * enqueued moves (source + output bytes of all its frames; 0 = unknown, taken as one frame): only launches of at most TSVPP_OVERLAP_MAX_BYTES alternate -- two
  * LARGE launches side by side lose (64-frame launches of the headline: 0.78 -> 0.67 of the roofline), so those stay on the consumer's first stream.  The second
  * stream is created on the consumer's first call with the option set (one hipStreamCreate).  tsvpp_consumer_synchronize waits (on the host) for everything
  * enqueued on the consumer's streams. */
-#define TSVPP_OVERLAP_MAX_BYTES ((size_t)128 << 20)
+#define TSVPP_OVERLAP_MAX_BYTES ((size_t)256 << 20)
+#define TSVPP_BARRIER_FREE_MAX_BYTES ((size_t)64 << 20) /* ... and only launches up to this size go out without the barrier bit (profiles/r06_curve_values.txt) */
 int tsvpp_consumer_next_stream(tsvpp_ctx *ctx, const char *name, size_t launch_bytes, void **out_stream);
 int tsvpp_consumer_synchronize(tsvpp_ctx *ctx, const char *name);
 

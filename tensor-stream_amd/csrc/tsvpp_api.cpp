@@ -1081,9 +1081,10 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     const bool from_table = tab.y != nullptr && !two_pass;
     // TSVPP_OPT_INPUTS_READY: never out of a table (tsvpp_table_set's upload is enqueued on this stream: the launch must wait for it), never for the two-pass
     // formats (pass 1 writes the stream's scratch buffer, which the previous call's pass 2 may still be reading)
-    // ... and only for launches small enough to gain from running beside their predecessor (TSVPP_OVERLAP_MAX_BYTES)
+    // ... and only for launches small enough to gain from starting beside their predecessor: measured on the headline (profiles/r06_curve_values.txt, one consumer on two
+    // streams) 1 / 2 / 4 frames per launch 0.367 / 0.573 / 0.661 -> 0.410 / 0.583 / 0.682 of the roofline, but 8 frames (113 MB) 0.719 -> 0.682
     d.any_order = ((ctx->inputs_ready == 1 || ctx->inputs_ready == 2) && tab.y == nullptr && !two_pass &&
-                   (size_t)n * ((size_t)pl.src_w * pl.src_h * 3 / 2 + pl.out_bytes) <= TSVPP_OVERLAP_MAX_BYTES) ? 1 : 0;
+                   (size_t)n * ((size_t)pl.src_w * pl.src_h * 3 / 2 + pl.out_bytes) <= TSVPP_BARRIER_FREE_MAX_BYTES) ? 1 : 0;
     int max_launch = TSVPP_MAX_BATCH;
     if (from_table) {
         const long wg_per_frame = (long)((pl.dst_w + 63) / 64) * ((pl.dst_h + 3) / 4);

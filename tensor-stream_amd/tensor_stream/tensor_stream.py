@@ -131,6 +131,36 @@ class FrameRing:
                 return None, -1
             return [self.frames[aligned]] * len(names), self.current
 
+    def get_batch(self, name, k, index=0, timeout=None):
+        """The consumer's next hand-off as a TEMPORAL window: the frame get() would return and the k - 1 frames published before it, oldest first ->
+        ([k frames], frame_number of the newest).  Frames are addressed by their absolute number (frame f lives in slot f mod depth): the window
+        [newest - k + 1, newest] must still be in the ring (k - index <= depth) and already published, else (None, -1) = VREADER_REPEAT, as get() answers for a
+        delay that reaches before the first frame."""
+        k = int(k)
+        if k < 1 or k - min(int(index), 0) > self.depth:
+            raise ValueError(f"batch={k}, delay={index}: the ring holds {self.depth} frames")
+        with self.cv:
+            if name not in self.status:
+                self.status[name] = self.current > 0
+            deadline = None if timeout is None else time.monotonic() + timeout
+            while not self.finished and not self.status[name]:
+                if not self.cv.wait(None if deadline is None else max(0.0, deadline - time.monotonic())):
+                    if deadline is not None and time.monotonic() >= deadline:
+                        raise RuntimeError("Timeout waiting for a frame")
+            if self.finished:
+                raise RuntimeError("Decoding finished")
+            self.status[name] = False
+            self.cv.notify_all()
+            index = min(int(index), 0)
+            newest = self.current - 1 + index
+            oldest = newest - k + 1
+            if oldest < 0 or oldest <= self.current - 1 - self.depth:
+                return None, -1
+            frames = [self.frames[f % self.depth] for f in range(oldest, newest + 1)]
+            if any(f is None for f in frames):
+                return None, -1
+            return frames, self.current
+
     def all_consumed(self):
         with self.cv:
             return all(not v for v in self.status.values()) and len(self.status) > 0
@@ -374,14 +404,27 @@ class TensorStreamConverter:
 
     # ---- reading ---------------------------------------------------------------------------------
     def read(self, name="default", width=0, height=0, resize_type=ResizeType.NEAREST, crop_coords=(0, 0, 0, 0), pixel_format=FourCC.RGB24,
-             planes_pos=Planes.MERGED, normalization=None, delay=0, return_index=False):
+             planes_pos=Planes.MERGED, normalization=None, delay=0, return_index=False, batch=None):
+        """The reference's read() (tensor_stream/tensor_stream.py:248-273) plus `batch` (round 6): batch=k (1 <= k <= buffer_size) returns the consumer's next
+        frame TOGETHER with the k - 1 frames before it -- the decoder ring already holds them (reference include/Decoder.h:19, tensor_stream.py:165) -- as one
+        (k, ...) tensor, oldest first, converted by ONE tsvpp_convert_batch launch: a clip for a temporal model, at 0.6-0.7 of the HBM roofline for k = 4..8
+        where k single-frame reads run at 0.27 (profiles/r06_curve_*.txt).  return_index gives the index of the newest frame."""
         fp = FrameParameters(width=width, height=height, crop_coords=crop_coords, resize_type=resize_type, pixel_format=pixel_format,
                              planes_pos=planes_pos, normalization=normalization)
-        return self.param_read(fp, name=name, delay=delay, return_index=return_index)
+        return self.param_read(fp, name=name, delay=delay, return_index=return_index, batch=batch)
 
-    def param_read(self, frame_parameters, name="default", delay=0, return_index=False):
+    def param_read(self, frame_parameters, name="default", delay=0, return_index=False, batch=None):
         if self._ring is None or self._vpp is None:
             raise RuntimeError("-3")  # the reference throws std::to_string(VREADER_ERROR) when the pipeline is not up
+        if batch is not None:
+            if not 1 <= int(batch) <= self.buffer_size:
+                raise RuntimeError(f"-3: batch={batch} exceeds the decoder ring (buffer_size={self.buffer_size})")
+            self._vpp.consumer_stream(name)  # claims the consumer's pool slot, as every read does
+            frames, index = None, -1
+            while frames is None:  # VREADER_REPEAT until the ring holds k frames
+                frames, index = self._ring.get_batch(name, int(batch), delay, self._timeout)
+            tensor = self._convert_group(frames, frame_parameters)
+            return (tensor, index) if return_index else tensor
         frame, index = None, -1
         while frame is None:  # VREADER_REPEAT loop of TensorStream::getFrame (src/Wrappers/WrapperPython.cpp:300-306)
             frame, index = self._ring.get(name, delay, self._timeout)

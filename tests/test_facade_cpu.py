@@ -195,3 +195,31 @@ def test_coalescer_groups_concurrent_requests_and_returns_each_its_slice():
     for t in th:
         t.join(timeout=5)
     assert out == ["boom"] * 4
+
+
+def test_ring_get_batch_returns_the_temporal_window_oldest_first():
+    """read(batch=k): the consumer's next frame with the k - 1 frames before it (absolute frame numbers: frame f lives in slot f mod depth)."""
+    from tensor_stream.tensor_stream import FrameRing
+    ring = FrameRing(5)
+    ring.publish("f0")
+    assert ring.get_batch("c", 1) == (["f0"], 1)
+    ring.publish("f1")
+    assert ring.get_batch("c", 3) == (None, -1)               # only two frames exist: VREADER_REPEAT ...
+    ring.publish("f2")
+    assert ring.get_batch("c", 3) == (["f0", "f1", "f2"], 3)  # ... until the ring holds three
+    for k in range(3, 9):
+        ring.publish(f"f{k}")
+    assert ring.get_batch("c", 5) == (["f4", "f5", "f6", "f7", "f8"], 9)   # wrapped around the ring, still oldest first
+    ring.publish("f9")
+    assert ring.get_batch("c", 2, -2) == (["f6", "f7"], 10)    # delay moves the window's newest frame back
+    ring.publish("f10")
+    assert ring.get_batch("c", 4, -1) == (["f6", "f7", "f8", "f9"], 11)   # 4 + 1 = 5 frames back: just inside the ring
+    with pytest.raises(ValueError):
+        ring.get_batch("c", 6)                                 # more than the ring holds
+    with pytest.raises(ValueError):
+        ring.get_batch("c", 4, -2)                             # window reaches past the ring
+    with pytest.raises(RuntimeError, match="Timeout"):
+        ring.get_batch("c", 1, 0, timeout=0.05)                # every published frame has been handed to "c"
+    ring.finish()
+    with pytest.raises(RuntimeError, match="Decoding finished"):
+        ring.get_batch("c", 1)
