@@ -203,7 +203,7 @@ int main(int argc, char **argv) {
             for (int t = 0; t < max_t; t++) CK(hipMemsetAsync(pool[(size_t)t].out, 0xCD, out_stride * per_thread, nullptr));
             CK(hipDeviceSynchronize());
             // launch i of a thread converts its frames [(i n) mod F, +n) on its stream i mod S
-            const size_t launch_bytes = (size_t)n * ((size_t)W * H * 3 / 2 + out_bytes);
+            const size_t launch_bytes = (size_t)((double)n * moved); // what the caller knows the launch moves
             auto issue = [&](Slice &s, long i, int t = 0) {
                 const int base = (int)((i * (long)n) % s.frames);
                 void *st = s.streams[(size_t)(i % S)];

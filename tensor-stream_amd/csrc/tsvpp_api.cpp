@@ -628,6 +628,20 @@ int scratch_grow(tsvpp_ctx *ctx, tsvpp_ctx::ScratchSlot *slot, size_t need) {
     return TSVPP_OK;
 }
 size_t scratch_frame_bytes(const Plan &pl) { return (((size_t)pl.dst_w * pl.dst_h * 3 / 2) + 255) & ~(size_t)255; }
+// Bytes one frame of this request moves, roughly: the output + the source rows its sampler taps (a point sampler at vertical ratio r reads every r-th row,
+// the 2-tap kernels two of every r, BICUBIC four: C4's 4K -> 720p point sample 6.9 MB where the ROI formula says 15.2; PMC: 6.91 MB).  Only used to decide whether a
+// launch is small enough to overlap its predecessor (TSVPP_BARRIER_FREE_MAX_BYTES).
+size_t plan_moved_bytes(const Plan &pl) {
+    double rows = 1.0;
+    if (pl.yr > 1.0f) {
+        if (pl.mode == M_NEAREST || pl.point_kind != PK_NONE) rows = 1.0 / pl.yr;
+        else if (pl.mode == M_BILINEAR || pl.mode == M_AREA_UP) rows = 2.0 / pl.yr;
+        else if (pl.mode == M_BICUBIC) rows = 4.0 / pl.yr;
+    }
+    if (rows > 1.0) rows = 1.0;
+    return pl.out_bytes + (size_t)((double)pl.src_w * pl.src_h * 1.5 * rows);
+}
+
 bool needs_scratch(const Plan &pl) { return (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && pl.mode != M_NONE; }
 
 // ---- replay of a thread's recent launches (round 6) ---------------------------------------------------------------------------------------------------
@@ -1084,7 +1098,7 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
     // ... and only for launches small enough to gain from starting beside their predecessor: measured on the headline (profiles/r06_curve_values.txt, one consumer on two
     // streams) 1 / 2 / 4 frames per launch 0.367 / 0.573 / 0.661 -> 0.410 / 0.583 / 0.682 of the roofline, but 8 frames (113 MB) 0.719 -> 0.682
     d.any_order = ((ctx->inputs_ready == 1 || ctx->inputs_ready == 2) && tab.y == nullptr && !two_pass &&
-                   (size_t)n * ((size_t)pl.src_w * pl.src_h * 3 / 2 + pl.out_bytes) <= TSVPP_BARRIER_FREE_MAX_BYTES) ? 1 : 0;
+                   (size_t)n * plan_moved_bytes(pl) <= TSVPP_BARRIER_FREE_MAX_BYTES) ? 1 : 0;
     int max_launch = TSVPP_MAX_BATCH;
     if (from_table) {
         const long wg_per_frame = (long)((pl.dst_w + 63) / 64) * ((pl.dst_h + 3) / 4);
