@@ -458,6 +458,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true", help="skip the NEAREST/BICUBIC/AREA side measurements of the headline")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--warmup-ms", type=float, default=40.0, help="time-based warm-up after the --warmup steps: untimed steps until the device has worked this long (clock ramp)")
+    ap.add_argument("--consumers", type=int, default=0, help="C5 AS BASELINE.json WORDS IT (\"64 concurrent consumers, 8x MI355X\"): the step is ONE TensorStreamConverter.read_many over "
+                    "consumers / world NAMED consumers of this rank's own converter (synthetic 4K source, one pooled stream per consumer name, reference src/VideoProcessor.cpp:98-104) "
+                    "instead of a C-ABI batch over pre-built descriptors; --workload c5 --consumers 64 --gpus N.  consumers must be a multiple of the world size")
     ap.add_argument("--curve-only", default=None, help="run only the launch-curve leg (1 .. 64 frames per launch, tensor-stream_amd/cpp/vpp_curve.cpp) for these workloads, "
                     "comma separated (e.g. headline,c3,c4), print its JSON and exit")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to the CPUs local to its GPU")
@@ -567,6 +570,97 @@ class StubEngine:
 
     def close(self):
         pass
+
+
+class FacadeEngine:
+    """--consumers C: the production entry as the engine of the timed region.  Each rank owns one TensorStreamConverter on a synthetic source of the workload's size
+    (a pool of distinct frames three times the Infinity Cache, uploaded once) with C / world named consumers; a step = one read_many(names) = one hand-off under one
+    lock + ONE batched launch + one output tensor, every consumer its own view (tensor_stream/tensor_stream.py).  StubFacadeEngine is its CPU twin (launch plumbing tests)."""
+
+    def __init__(self, args, spec, rank, world, dev, dist):
+        import torch
+        import tensor_stream as ts
+        from tensor_stream import parallel
+        self.torch, self.ts, self.dev, self.rank, self.args, self.spec = torch, ts, dev, rank, args, spec
+        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = spec
+        if args.consumers % world:
+            raise RuntimeError(f"--consumers {args.consumers} is not a multiple of the world size {world}")
+        self.n = args.consumers // world
+        self.names = [f"consumer{rank * self.n + i}" for i in range(self.n)]  # global consumer ids: consumer c lives on rank c // (C / world)
+        self.pool = max(8, -(-(768 << 20) // (src_w * src_h * 3 // 2)))
+        self.seed = 300 + rank
+        self.conv = ts.TensorStreamConverter(f"synthetic://{src_w}x{src_h}?seed={self.seed}&frames=0&fps=100000&pool={self.pool}", max_consumers=self.n, cuda_device=dev,
+                                             framerate_mode=ts.FrameRate.FAST)
+        self.conv.initialize()
+        self.coeffs = parallel.broadcast_coeffs(self.conv._vpp, dist)
+        self.coeff_broadcast = parallel.last_broadcast_info()
+        self.conv.start()
+        self.kw = dict(width=dst[0], height=dst[1], resize_type=RESIZE[rt], crop_coords=crop, pixel_format=FOURCC[fcc], planes_pos=PLANES[planes], normalization=norm)
+        self.fp = ts.FrameParameters(**self.kw)
+        self.frames_per_launch = float(self.n)
+        self.launches_per_step = 1
+        self.ws_mib = self.pool * src_w * src_h * 1.5 / 2**20
+        self.parity = "skipped"
+        self.graphs = []
+        self.extra_streams = []
+        self.cur_stream = torch.cuda.current_stream(dev).cuda_stream
+        self.last = None
+
+    def step(self, i):
+        self.last = self.conv.read_many(self.names, **self.kw)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, first, work=None):
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            self.step(first + i)
+        ev1.record()
+        host_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1), host_issue
+
+    def check_parity(self, last_step, work=None):
+        """One more read_many with its frame index: the first and the last consumer's tensors against the oracle's conversion of that pool frame."""
+        from oracle import oracle as O
+        from tensor_stream.sources import open_source
+        src_w, src_h, pitch, crop, dst, rt, fcc, planes, norm = self.spec
+        tensors, index = self.conv.read_many(self.names, return_index=True, **self.kw)
+        self.torch.cuda.synchronize()
+        src = open_source(f"synthetic://{src_w}x{src_h}?seed={self.seed}&frames=0&pool={self.pool}")
+        y, uv = src.pool[(index - 1) % self.pool]
+        ref, _, _ = O.convert(y, uv, crop=crop, dst=dst, resize_type=RESIZE[rt], fourcc=FOURCC[fcc], planes=PLANES[planes], normalization=norm, nthreads=min(16, O.host_cores()))
+        ok = all(np.array_equal(t.cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)) for t in (tensors[0], tensors[-1]))
+        return ok, (f"bit-exact vs oracle (consumers {self.names[0]} / {self.names[-1]} of one read_many after the timed region, frame {index})" if ok else "MISMATCH vs oracle")
+
+    def kernel_name(self):
+        try:
+            dsc = self.ts.vpp.describe(self.fp, self.spec[0], self.spec[1], pitch=self.spec[0], n_frames=int(self.n))
+            return "tsvpp::" + str(dsc.get("kernel", "?"))
+        except Exception as e:  # noqa: BLE001
+            return f"tsvpp::? ({type(e).__name__}: {e})"
+
+    def side_work(self, spec, sets=2, batch=None, table=False):
+        raise RuntimeError("no side legs in --consumers mode")
+
+    def close(self):
+        self.conv.stop()
+
+
+class StubFacadeEngine(StubEngine):
+    """TSVPP_BENCH_STUB=1 --consumers C: C / world named consumers per rank, a step is a short sleep (tests of the sharding / reduction plumbing at world 8)."""
+
+    def __init__(self, args, spec, rank, world):
+        if args.consumers % world:
+            raise RuntimeError(f"--consumers {args.consumers} is not a multiple of the world size {world}")
+        self.n = args.consumers // world
+        self.names = [f"consumer{rank * self.n + i}" for i in range(self.n)]
+        args.batch = self.n
+        super().__init__(args, spec, rank)
 
 
 class GpuWork:
@@ -871,7 +965,7 @@ def run(args):
         if stub:
             def make_stub():
                 injected("engine")
-                return StubEngine(args, spec, rank)
+                return StubFacadeEngine(args, spec, rank, world) if args.consumers else StubEngine(args, spec, rank)
             eng = step_of("engine", make_stub)
         else:
             import torch
@@ -882,6 +976,8 @@ def run(args):
 
             def make_engine():
                 injected("engine")
+                if args.consumers:
+                    return FacadeEngine(args, spec, rank, world, dev, dist)
                 return GpuEngine(args, spec, rank, dev, dist)  # context, coefficient broadcast (the one collective), buffer fill, descriptor tables
             eng = step_of("engine", make_engine)
     except Exception as e:  # noqa: BLE001 -- anything: the other ranks must learn about it
@@ -905,6 +1001,8 @@ def run(args):
     setup_s = round(time.perf_counter() - t_setup, 3)
     log(f"set-up complete in {setup_s:.3f} s")
 
+    if args.consumers:
+        args.batch = eng.n  # frames per step = this rank's consumers
     B = args.batch
 
     def bytes_of(sp):
@@ -993,8 +1091,11 @@ def run(args):
     if dist is not None:
         rates = gather(B * args.steps / mine_reps[med][0])
         issue = gather(mine_reps[med][2] * 1e3 / args.steps)
+        # every rank's own roofline fraction (its launch stream's HIP events): a slow GPU or a host-bound rank shows here, not in the max-over-ranks wall clock
+        fracs = gather(bytes_per_frame * eng.frames_per_launch / (mine_reps[med][1] / (args.steps * eng.launches_per_step) * 1e-3) / 1e9 / HBM_PEAK_GBS if mine_reps[med][1] > 0 else 0.0)
         per_rank = {"min_frames_per_s": round(min(rates), 1), "max_frames_per_s": round(max(rates), 1),
-                    "frames_per_s": [round(x, 1) for x in rates], "host_issue_ms_per_step": [round(x, 4) for x in issue],
+                    "frames_per_s": [round(x, 1) for x in rates], "roofline_frac": [round(x, 4) for x in fracs],
+                    "host_issue_ms_per_step": [round(x, 4) for x in issue],
                     "setup_s": [round(x, 3) for x in gather(setup_s)], "rank0_setup_steps": setup_log,
                     "backend": backend, "rank0_affinity": affinity}
 
@@ -1054,7 +1155,7 @@ def run(args):
             return {"error": f"{type(e).__name__}: {e}"}
 
     others, other_wl = None, None
-    if (not stub or dist is not None) and name == "headline" and not args.resize and not args.no_others:
+    if (not stub or dist is not None) and name == "headline" and not args.resize and not args.no_others and not args.consumers:
         others = {}
         for rname in ("NEAREST", "BICUBIC", "AREA"):
             sp = list(spec)
@@ -1093,6 +1194,9 @@ def run(args):
                          "kernel": eng.kernel_name() if not stub else "stub", "bytes_per_frame": bytes_per_frame,
                          "avg_launch_ms": round(kernel_ms, 5), "host_issue_ms_per_step": round(host_issue * 1e3 / args.steps, 4)},
         }
+        if args.consumers:
+            res["config"]["consumers"] = {"total": args.consumers, "per_rank": eng.n, "entry": "TensorStreamConverter.read_many (one batched launch per published frame)",
+                                          "names_rank0": [eng.names[0], eng.names[-1]], "sharding": "consumer c -> rank c // (consumers / world): each rank its own converter, source and stream pool"}
         if per_rank:
             res["per_rank"] = per_rank
         if dist is not None and not stub:
@@ -1151,9 +1255,10 @@ def run(args):
             res["config"]["other_resize_types"] = others
         if other_wl is not None:
             res["config"]["other_workloads"] = other_wl
-        if world == 1 and not args.no_cpu_baseline:
+        # (round 6) N > 1 lines carry it too: rank 0 measures it here, after every timed region, while the other ranks wait in the final barrier
+        if not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(spec, budget_s=args.cpu_budget, tight_pitch=args.tight_pitch)
+                res["cpu_baseline"] = cpu_baseline(spec, budget_s=(min(args.cpu_budget, 0.3) if stub else args.cpu_budget), tight_pitch=args.tight_pitch)
             except Exception as e:
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "swscale": "unavailable in image"}
         if out_fd is not None:

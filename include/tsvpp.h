@@ -141,10 +141,12 @@ int tsvpp_convert_batch(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
  * TSVPP_MAX_TABLE_LAUNCH frames: the small-output configurations (BASELINE C3: 1.8 MB per frame) move 0.64 of the HBM roofline in 64-frame launches and
  * 0.70+ from 256 frames on (profiles/r05_table_ab.txt); nothing is copied per call.
  *   tsvpp_table_create    `capacity` entries; every entry shares one geometry (width, height, pitches: fixed by the first tsvpp_table_set).
- *   tsvpp_table_set       entries [first, first + n) <- in[i] / outs[i] (HOST arrays); uploaded on `stream` out of a pinned mirror the table owns: the arrays may be
- *                         freed on return, conversions enqueued on the same stream afterwards see the new entries.
+ *   tsvpp_table_set       entries [first, first + n) <- in[i] / outs[i] (HOST arrays); uploaded on `stream` out of pinned staging the table owns (one slot per
+ *                         upload in flight, four slots: a fifth concurrent upload waits for the oldest): the arrays may be freed on return, conversions enqueued
+ *                         on the same stream afterwards see the new entries, conversions enqueued BEFORE it see the old ones.
  *   tsvpp_convert_table   == tsvpp_convert_batch over entries [first, first + n), same results, same status codes.
- *   tsvpp_table_destroy   frees the table (the caller has waited for conversions that use it).
+ *   tsvpp_table_destroy   frees the table (the caller has waited for conversions that use it).  Destroying the CONTEXT first is legal: tsvpp_destroy releases the
+ *                         device memory of its live tables, their handles remain valid arguments of tsvpp_table_destroy only.
  * A table belongs to the context that created it (its device).  tsvpp_table_set calls are serialised against each other; a tsvpp_convert_table that runs
  * concurrently with a tsvpp_table_set of the SAME entries from another thread is the caller's race (as two writers of one AVFrame would be), and a captured
  * hipGraph replays the table as the device holds it at replay time (entries are read by the kernels, not baked into the graph). */
@@ -201,12 +203,24 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on);
  * Results are identical either way.
  * Value: 0 = off; 1 = on; (2 / 3: A-B values -- 2 = barrier-free launches without the second stream, 3 = the second stream without barrier-free launches). */
 #define TSVPP_OPT_INPUTS_READY 1
+/* TSVPP_OPT_COLOR_G_TERM (default 0).  The colour conversion's green chroma term `-0.813 (V-128) - 0.391 (U-128)` (reference src/ColorConversion.cu:30-35) is
+ * the one place of the path where the reference's result depends on how nvcc contracted the expression AND no golden of the reference decides it (DESIGN.md
+ * section 2; 36 of the 2^24 (Y, U, V) triples differ by one in G between the variants, R and B never):
+ *   0  fma(-0.813, V-128, -(0.391 (U-128)))   the LLVM fadd -> fma rule that the resize goldens pin, applied here (the default since 0.3.0)
+ *   1  (-0.813 (V-128)) - (0.391 (U-128))     plain IEEE, both products rounded (the library's output until 0.2.x)
+ *   2  fma(-0.391, U-128, -0.813 (V-128))     the right-hand product fused
+ * for whoever holds goldens of the real reference binary (tools/ref_capture/ produces them on an NVIDIA box).  Same speed; every kernel honours it. */
+#define TSVPP_OPT_COLOR_G_TERM 2
+/* TSVPP_OPT_UNSAFE_COEFFS (default 0): tsvpp_set_coeffs refuses (TSVPP_UNSUPPORTED) a block that differs from tsvpp_default_coeffs by a single bit unless this is
+ * set -- the library's parity statements are about the reference's literals. */
+#define TSVPP_OPT_UNSAFE_COEFFS 3
 #define TSVPP_HAVE_OPTIONS 1
 int tsvpp_set_option(tsvpp_ctx *ctx, int option, int value);
 int tsvpp_get_option(const tsvpp_ctx *ctx, int option, int *value);
 
 /* Colour constants: read the active block, replace it (e.g. with the block received
- * from rank 0), restore the defaults. */
+ * from rank 0), restore the defaults.  tsvpp_set_coeffs accepts only the default block (bit for bit) unless
+ * TSVPP_OPT_UNSAFE_COEFFS is set: TSVPP_UNSUPPORTED otherwise. */
 int tsvpp_get_coeffs(const tsvpp_ctx *ctx, tsvpp_coeffs *out);
 int tsvpp_set_coeffs(tsvpp_ctx *ctx, const tsvpp_coeffs *in);
 void tsvpp_default_coeffs(tsvpp_coeffs *out);

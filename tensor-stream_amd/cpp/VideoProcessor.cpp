@@ -180,12 +180,37 @@ int VideoProcessor::Convert(AVFrame *input, AVFrame *output, FrameParameters &op
     const size_t bytes = tsvpp_out_bytes(&p, input->width, input->height);
     int w = 0, h = 0;
     CHECK_STATUS(tsvpp_out_dims(&p, input->width, input->height, &w, &h)); // also the error path of out_bytes == 0
+    // the result buffer: one that Release() took back (same size), else a fresh allocation -- reference ownership either way: the caller frees output->opaque
+    // (hipFree) or hands it back (Release)
     void *dst = nullptr;
-    CHECK_STATUS((int)hipMalloc(&dst, bytes)); // reference ownership: the caller frees output->opaque
+    hipEvent_t released = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(poolSync);
+        auto it = pool.find(bytes);
+        if (it != pool.end() && !it->second.empty()) {
+            dst = it->second.back().ptr;
+            released = it->second.back().released;
+            it->second.pop_back();
+        }
+    }
+    if (!dst) CHECK_STATUS((int)hipMalloc(&dst, bytes));
+    if (released) { // the consumer's streams wait for the releasing stream's last use of the buffer (no host synchronisation)
+        void *s0 = nullptr;
+        if (tsvpp_consumer_stream(ctx, consumerName.c_str(), &s0) == 0) (void)hipStreamWaitEvent((hipStream_t)s0, released, 0);
+        int ready = 0;
+        if (tsvpp_get_option(ctx, TSVPP_OPT_INPUTS_READY, &ready) == 0 && ready) (void)hipEventSynchronize(released); // (two streams, barrier-free launches: the promise is "nobody uses the output")
+        std::lock_guard<std::mutex> lk(poolSync);
+        spareEvents.push_back(released);
+    }
     int sts = ConvertInto(input, dst, options, consumerName);
     if (sts != VREADER_OK) {
         (void)hipFree(dst);
         return sts;
+    }
+    {
+        std::lock_guard<std::mutex> lk(poolSync);
+        if (handedOut.size() > 65536) handedOut.clear(); // a caller that only ever hipFree()s leaves its entries behind: bounded (Release then answers VREADER_ERROR for the forgotten ones)
+        handedOut[dst] = bytes;
     }
     output->opaque = dst;
     output->width = w;
@@ -232,8 +257,46 @@ template <class T> int VideoProcessor::DumpFrame(T *output, FrameParameters opti
 template int VideoProcessor::DumpFrame(float *, FrameParameters, std::shared_ptr<FILE>);
 template int VideoProcessor::DumpFrame(uint8_t *, FrameParameters, std::shared_ptr<FILE>);
 
+int VideoProcessor::Release(void *opaque, hipStream_t stream) {
+    if (isClosed || !opaque) CHECK_STATUS(VREADER_ERROR);
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(poolSync);
+        auto it = handedOut.find(opaque);
+        if (it == handedOut.end()) CHECK_STATUS(VREADER_ERROR); // not a result of this processor's Convert (or released twice)
+        bytes = it->second;
+        handedOut.erase(it);
+        if (!spareEvents.empty()) {
+            ev = spareEvents.back();
+            spareEvents.pop_back();
+        }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, stream) != hipSuccess) { // cannot order the reuse: fall back to the reference's contract
+        if (ev) (void)hipEventDestroy(ev);
+        CHECK_STATUS((int)hipFree(opaque));
+        return VREADER_OK;
+    }
+    std::lock_guard<std::mutex> lk(poolSync);
+    pool[bytes].push_back(Pooled{ opaque, ev });
+    return VREADER_OK;
+}
+
 void VideoProcessor::Close() {
     if (isClosed) return;
+    {
+        std::lock_guard<std::mutex> lk(poolSync);
+        for (auto &kv : pool)
+            for (Pooled &b : kv.second) {
+                (void)hipFree(b.ptr);
+                (void)hipEventDestroy(b.released);
+            }
+        pool.clear();
+        for (hipEvent_t e : spareEvents) (void)hipEventDestroy(e);
+        spareEvents.clear();
+        handedOut.clear(); // (buffers the caller still holds are the caller's to hipFree)
+    }
     tsvpp_destroy(ctx);
     ctx = nullptr;
     isClosed = true;

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #if defined(__has_include)
@@ -114,6 +115,12 @@ public:
     // Same conversion into caller-owned memory (no allocation at all) -- what a torch-backed
     // getFrame should call with tensor.data_ptr().
     int ConvertInto(AVFrame *input, void *deviceOut, FrameParameters &options, std::string consumerName, int *outWidth = nullptr, int *outHeight = nullptr);
+    // Hands a result of Convert (output->opaque) BACK to the processor instead of hipFree()ing it (round 6).  hipFree stays legal -- it is the reference's
+    // contract (c_examples/src/Sample.cpp:27,36) -- but it costs a device-wide synchronisation and the next Convert a hipMalloc: 120-180 us a frame with millisecond
+    // outliers, where the conversion itself takes ~6.  A released buffer is reused by the next Convert that needs the same number of bytes: no allocator call in
+    // the steady state.  `stream`: the stream on which the caller's LAST use of the buffer was enqueued (nullptr = the legacy default stream); the reuse is ordered
+    // behind an event recorded there, nothing is synchronised.  Buffers still pooled at Close() are freed.  VREADER_ERROR for a pointer Convert did not hand out.
+    int Release(void *opaque, hipStream_t stream = nullptr);
     template <class T> int DumpFrame(T *output, FrameParameters options, std::shared_ptr<FILE> dumpFile);
     void Close();
     ~VideoProcessor() { Close(); }
@@ -123,6 +130,12 @@ private:
     bool enableDumps = false;
     tsvpp_ctx *ctx = nullptr;
     std::mutex dumpSync;
+    // result buffers: what Convert handed out (pointer -> bytes) and what Release took back (bytes -> buffers, each with the event of its release)
+    struct Pooled { void *ptr; hipEvent_t released; };
+    std::mutex poolSync;
+    std::unordered_map<void *, size_t> handedOut;
+    std::unordered_map<size_t, std::vector<Pooled>> pool;
+    std::vector<hipEvent_t> spareEvents;
     bool isClosed = true;
     std::shared_ptr<Logger> logger;
 };

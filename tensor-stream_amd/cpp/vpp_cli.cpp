@@ -59,7 +59,25 @@ int main(int argc, char **argv) {
     FILE *o = fopen(outPath, "wb");
     fwrite(res.data(), 1, n, o);
     fclose(o);
-    printf("ok %d %d second=%d third=%d input_unref=%d\n", out->width, out->height, s2, s3, in->data[0] == nullptr ? 1 : 0);
+    // Release(): the result handed back instead of freed -> the next Convert of the same size gets the same buffer (no allocator call) and the same bytes;
+    // a pointer Convert never handed out, or one released twice, is VREADER_ERROR; hipFree of a result stays legal (reference contract)
+    void *first = out->opaque;
+    const int r1 = vpp.Release(first);
+    *in2 = AVFrame();
+    in2->data[0] = dY; in2->data[1] = dUV; in2->linesize[0] = in2->linesize[1] = pitch; in2->width = W; in2->height = H;
+    FrameParameters p3 = params;
+    const int s4 = vpp.Convert(in2, out, p3, "cli");
+    (void)hipDeviceSynchronize();
+    std::vector<uint8_t> res2(n);
+    if (s4 == 0) (void)hipMemcpy(res2.data(), out->opaque, n, hipMemcpyDeviceToHost);
+    const int reuse = (s4 == 0 && out->opaque == first) ? 1 : 0, same = (s4 == 0 && res2 == res) ? 1 : 0;
+    const int r_foreign = vpp.Release((void *)dY), r_twice = (vpp.Release(out->opaque) == 0) ? vpp.Release(out->opaque) : 99;
+    *in2 = AVFrame();
+    in2->data[0] = dY; in2->data[1] = dUV; in2->linesize[0] = in2->linesize[1] = pitch; in2->width = W; in2->height = H;
+    const int s5 = vpp.Convert(in2, out, p3, "cli"); // (takes the pooled buffer again; freed below the reference's way)
+    printf("ok %d %d second=%d third=%d input_unref=%d release=%d reuse=%d same=%d foreign=%d twice=%d again=%d\n", out->width, out->height, s2, s3, in->data[0] == nullptr ? 1 : 0, r1,
+           reuse, same, r_foreign, r_twice, s5);
+    (void)hipDeviceSynchronize();
     (void)hipFree(out->opaque);
     vpp.Close();
     (void)hipFree(dY);

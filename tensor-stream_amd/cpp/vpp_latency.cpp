@@ -3,6 +3,7 @@
 // resident in device memory, `iters` conversions, each timed on the host from the call to the end of hipStreamSynchronize on the consumer's stream:
 //   convert       VideoProcessor::Convert as the reference's contract has it: the result is a fresh device buffer the caller frees (hipMalloc + hipFree
 //                 per frame, like the reference's cudaMalloc / cudaFree)
+//   convert_release  the same Convert, the result handed back with VideoProcessor::Release instead of hipFree: no allocator call in the steady state
 //   convert_into  VideoProcessor::ConvertInto: caller-owned output, no allocation (what a torch-backed getFrame passes: tensor.data_ptr())
 //   graph         the same launch captured once into a hipGraph on the consumer's stream and replayed
 //   eager8 / graph8   eight conversions (eight ring slots) issued back to back + ONE synchronisation, directly and as one eight-node graph: hipGraphLaunch has a fixed
@@ -74,7 +75,7 @@ int main(int argc, char **argv) {
     AVFrame *in = av_frame_alloc(), *out = av_frame_alloc();
     const int ow = ow0, oh = oh0;
 
-    std::vector<double> t_alloc, t_into, t_graph;
+    std::vector<double> t_alloc, t_into, t_graph, t_release;
     const int warm = 200;
     for (int i = 0; i < warm + iters; i++) { // the reference's contract: fresh result buffer, freed by the caller
         fill(in);
@@ -84,6 +85,15 @@ int main(int argc, char **argv) {
         const double t1 = now_us();
         (void)hipFree(out->opaque);
         if (i >= warm) t_alloc.push_back(t1 - t0);
+    }
+    for (int i = 0; i < warm + iters; i++) { // ... and with the result handed back instead of freed
+        fill(in);
+        const double t0 = now_us();
+        if (vpp.Convert(in, out, params, "latency") != 0) return 10;
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        const double t1 = now_us();
+        if (vpp.Release(out->opaque, (hipStream_t)stream) != 0) return 13;
+        if (i >= warm) t_release.push_back(t1 - t0);
     }
     for (int i = 0; i < warm + iters; i++) {
         fill(in);
@@ -157,6 +167,8 @@ int main(int argc, char **argv) {
            planes, norm, iters);
     stats(t_alloc, p50, p99, mean, mn);
     printf(", \"convert_us\": {\"p50\": %.1f, \"p99\": %.1f, \"mean\": %.1f, \"min\": %.1f, \"note\": \"hipMalloc of the result inside, hipFree by the caller, like the reference\"}", p50, p99, mean, mn);
+    stats(t_release, p50, p99, mean, mn);
+    printf(", \"convert_release_us\": {\"p50\": %.1f, \"p99\": %.1f, \"mean\": %.1f, \"min\": %.1f, \"note\": \"the same Convert, the result handed back with VideoProcessor::Release instead of hipFree\"}", p50, p99, mean, mn);
     stats(t_into, p50, p99, mean, mn);
     printf(", \"convert_into_us\": {\"p50\": %.1f, \"p99\": %.1f, \"mean\": %.1f, \"min\": %.1f}", p50, p99, mean, mn);
     if (graph_ok && !t_graph.empty()) {

@@ -564,7 +564,7 @@ hipError_t launch_bicubic_cols(OutKind out, bool exact, const LaunchDesc &d, con
         info->kernel = exact ? (sparse ? "vpp_bicubic_cols_kernel<OUT, exact, sparse>" : "vpp_bicubic_cols_kernel<OUT, exact, dense>")
                              : (sparse ? "vpp_bicubic_cols_kernel<OUT, tie, sparse>" : "vpp_bicubic_cols_kernel<OUT, tie, dense>");
         info->grid = (int)grid.x;
-        info->lds_bytes = (int)lds_bytes;
+        info->lds_bytes = (int)lds_bytes + (out == O_U8_MERGED ? MAX_THREADS * 24 : 0); // + the static exchange slab of the uint8 merged output side
         return hipSuccess;
     }
     if (!d.bc_tab) return hipErrorInvalidValue;

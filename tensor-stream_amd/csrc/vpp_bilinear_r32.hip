@@ -401,7 +401,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         float t0[4], tg[4], t2[4];
         if constexpr (OUT == O_U8_PLANAR || OUT == O_U8_MERGED) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+            for (int c = 0; c < 4; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, d.color_g, t0[c], tg[c], t2[c]);
         }
         if constexpr (OUT == O_NV12_U8) {
             const uint32_t cpix = plane + (uint32_t)((i0 >> 1) + rc) * (uint32_t)d.dst_w + (uint32_t)j0;

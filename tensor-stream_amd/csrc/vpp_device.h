@@ -349,12 +349,23 @@ template <int OUT> constexpr bool kLumaOnly = (OUT == O_Y800_U8 || OUT == O_Y800
 //     GVal = fma(-0.813, V - 128, -(0.391 (U - 128))) + 0.5                                 (the subtraction's left product fused, the right one rounded)
 // and the luma product Y' = max(0, Y - 16) * 1.164 stays a rounded product (it feeds three sums).  R and B do not depend on the contraction for any
 // (Y, U, V); G differs from the plain-IEEE tree of rounds 1-4 by one on 36 of the 2^24 triples (tests/test_oracle_contract.py).
-__device__ __forceinline__ void chroma_terms(float Uf, float Vf, const tsvpp_coeffs &k, int swap_rb, float &t0, float &tg, float &t2) {
+// `g_term` (LaunchDesc::color_g, wave-uniform: a scalar branch) selects the other two trees of the green term for holders of goldens of the real reference binary
+// (TSVPP_OPT_COLOR_G_TERM, include/tsvpp.h): 1 = both products rounded, 2 = the right product fused.
+__device__ __forceinline__ void chroma_terms(float Uf, float Vf, const tsvpp_coeffs &k, int swap_rb, int g_term, float &t0, float &tg, float &t2) {
     f2 uv = { Uf, Vf };
     uv = uv - (f2){ k.c_offset, k.c_offset };
     const f2 br = __builtin_elementwise_fma(uv, (f2){ k.u_to_b, k.v_to_r }, (f2){ k.round_bias, k.round_bias }); // { 2.018 (U-128) + .5, 1.596 (V-128) + .5 }
-    const float gu = uv.x * k.u_to_g;                    // u_to_g < 0: -(0.391 (U-128)), rounded
-    const float gv = __builtin_fmaf(uv.y, k.v_to_g, gu); // -0.813 (V-128) - 0.391 (U-128): ONE rounding of the left product's sum
+    float gv;
+    if (g_term == 0) {
+        const float gu = uv.x * k.u_to_g;        // u_to_g < 0: -(0.391 (U-128)), rounded
+        gv = __builtin_fmaf(uv.y, k.v_to_g, gu); // -0.813 (V-128) - 0.391 (U-128): ONE rounding of the left product's sum
+    } else if (g_term == 1) {
+        const float g1 = uv.y * k.v_to_g, g2 = uv.x * k.u_to_g;
+        gv = g1 + g2;                            // == g1 - 0.391 (U-128): negation is exact
+    } else {
+        const float g1 = uv.y * k.v_to_g;
+        gv = __builtin_fmaf(uv.x, k.u_to_g, g1);
+    }
     tg = gv + k.round_bias;
     t0 = swap_rb ? br.x : br.y;
     t2 = swap_rb ? br.y : br.x;
@@ -751,7 +762,7 @@ __device__ __forceinline__ void color_store_tile(const float Yf[PXH][PXW], const
     }
     float t0[2], tg[2], t2[2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+    for (int c = 0; c < 2; c++) chroma_terms(Uf[c], Vf[c], d.k, d.swap_rb, d.color_g, t0[c], tg[c], t2[c]);
     // 32-bit element offsets from the frame's (uniform) base pointer: the stores use the
     // SGPR-base + VGPR-offset addressing mode instead of per-lane 64-bit pointer arithmetic
     // (host side guarantees 3 * W * H * sizeof(T) < 4 GiB)

@@ -83,6 +83,7 @@ struct LaunchDesc {
     int dst_w, dst_h;
     float xr, yr; // (float)src_w / dst_w, (float)src_h / dst_h   (src/Resize.cu:418-419)
     int swap_rb;  // BGR24
+    int color_g;  // TSVPP_OPT_COLOR_G_TERM: 0 left product of the green chroma term fused (default), 1 plain IEEE, 2 right product fused (chroma_terms, vpp_device.h)
     tsvpp_coeffs k;
     // AREA-down weight tables: nx rows of rx floats, ny rows of ry floats (rx = ceil(xr))
     const float *patx, *paty;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void r32_store_tile(const LaunchDesc &d, uint8_t *out
                     bc_unpack4(cx[k], uvf); // U0 V0 U1 V1
                     bc_unpack4(bc_dealt(deal, k, ylo[r], yhi[r]), yf);
 #pragma unroll
-                    for (int c = 0; c < 2; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+                    for (int c = 0; c < 2; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, d.color_g, t0[c], tg[c], t2[c]);
                     const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + run_j0 + 4u * (uint32_t)(k * run_a + run_m);
                     color_store_row<O_F32_PLANAR, true>(yf, t0, tg, t2, d.k, (float *)out, pix, plane, 4, nt, none);
                 }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void r32_store_tile(const LaunchDesc &d, uint8_t *out
             bc_unpack4(chi[rc], uvf + 4);
             float t0[4], tg[4], t2[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, t0[c], tg[c], t2[c]);
+            for (int c = 0; c < 4; c++) chroma_terms(uvf[2 * c], uvf[2 * c + 1], d.k, d.swap_rb, d.color_g, t0[c], tg[c], t2[c]);
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 const int r = 2 * rc + rr;

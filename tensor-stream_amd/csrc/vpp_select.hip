@@ -373,14 +373,15 @@ static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int strea
 }
 
 // 7. the LDS-staged kernels (2x2-tap, integer BICUBIC, dyadic / small float AREA): first workgroup shape, rows per thread and staging layout that fit
-static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gather, LaunchDesc &d, FusedSel &S) {
+static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gather, int stream_r32, LaunchDesc &d, FusedSel &S) {
     bool &staged = S.staged;
     size_t &lds_bytes = S.lds_bytes;
     int (&shapes)[5][2] = S.shapes;
     const size_t kLdsBudget = S.lds_budget;
     const bool f32_out = S.f32_out, two_tap = S.two_tap;
     auto workgroups = [&](const int *sh, int rpt) { return fused_workgroups(d, sh, rpt); };
-    if (!staged && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream && !d.bil_rows) {
+    // (a streaming kernel has been selected: nothing is staged -- ADVICE r05)
+    if (!staged && !stream_r32 && mode != M_NONE && vec && !d.force_gather && !d.area_direct && !sparse_gather && !d.area_stream && !d.bil_rows) {
         const int want_dma = d.dma;
         for (auto &sh : shapes) {
             if (sh[0] == 0 || staged) break;
@@ -491,13 +492,15 @@ static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gat
 }
 
 // 8. the wave-per-tile BICUBIC kernel
-static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, FusedSel &S, hipStream_t stream, LaunchInfo *info) {
+static void sel_bicubic_cols(Mode mode, OutKind out, bool vec, int stream_r32, LaunchDesc &d, FusedSel &S, hipStream_t stream, LaunchInfo *info) {
     bool &staged = S.staged;
     size_t &lds_bytes = S.lds_bytes;
     // BICUBIC that the integer kernel above did not take (non-dyadic weights -- or TSVPP_BICUBIC_COLS=2: every request): one wave per
     // 64-column tile, one lane per output column, H sums in a wave-private column-major LDS plane (vpp_bicubic_cols.hip).  A taller
     // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
-    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && !bc_r32) {
+    // (not when ANY streaming kernel took the request -- the BICUBIC ones at 3 : 2 / 2 : 1, or a point sampler at an integer ratio: its tables would be built,
+    // uploaded and cached for nothing)
+    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && !stream_r32) {
         const bool sparse = d.yr >= 4.0f;
         const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
         // LDS-DMA ring: a row segment is (64 columns at ratio xr + window + a misalignment of up to 15 bytes) rounded up to 16-byte chunks,
@@ -516,6 +519,9 @@ static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, Fus
             return 4 * ((((rows + 3) >> 2) + 1) | 1);
         };
         auto wave_bytes_of = [&](int r) { return ring_bytes + 64 * (col_stride(r) + r + r / 2); };
+        // the uint8 merged flavour's output side (r32_store_tile, vpp_r32_store.h) carries a STATIC exchange slab of MAX_THREADS x 24 bytes on top of the dynamic LDS,
+        // whether or not bc_u8x is chosen at run time: part of the workgroup's LDS for both budgets below and for info->lds_bytes
+        const int static_lds = out == O_U8_MERGED ? MAX_THREADS * 24 : 0;
         // Tile height, measured (profiles/r03_bicubic_cols_ab*.txt): 32 rows for up-scales (few source rows per tile: the seams cost
         // most there; 720p -> 1080p 0.519 against 0.502 at 16), 16 rows while the launch still has 8 waves per SIMD (1080p -> 640^2 0.620
         // against 0.609 at 8, 4K -> 1080p 0.651 against 0.624), else 8 (1080p -> 224^2 0.748 against 0.642, -> 300^2 0.404 against 0.367)
@@ -523,9 +529,9 @@ static void sel_bicubic_cols(Mode mode, bool vec, int bc_r32, LaunchDesc &d, Fus
         {
             auto waves_of = [&](int r) { return (long)((d.dst_w + 63) / 64) * ((d.dst_h + r - 1) / r) * d.n_frames; };
             int r = d.yr <= 1.0f ? 32 : 16;
-            while (r > 8 && (waves_of(r) < 32L * d.num_cus || 4 * wave_bytes_of(r) > 40 * 1024)) r -= 8;
+            while (r > 8 && (waves_of(r) < 32L * d.num_cus || 4 * wave_bytes_of(r) + static_lds > 40 * 1024)) r -= 8;
             if (d.bc_rows >= 8 && d.bc_rows <= 32 && (d.bc_rows & 7) == 0) r = d.bc_rows;
-            if (4 * wave_bytes_of(r) <= 64 * 1024) best_r = r;
+            if (4 * wave_bytes_of(r) + static_lds <= 64 * 1024) best_r = r;
         }
         // the request's column / row tables (host-built, cached in the context): a real launch -- and the dry run of
         // tsvpp_prepare_batch -- looks them up or builds them; while the stream is capturing and they do not exist yet the
@@ -592,7 +598,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
     const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
     sel_bilinear_rows(mode, vec, sparse_gather, stream_r32, d, S);
-    sel_staged(mode, vec, bicubic_staged, sparse_gather, d, S);
+    sel_staged(mode, vec, bicubic_staged, sparse_gather, stream_r32, d, S);
     if (d.tap22 && !staged) {
         //  sel_tap22 turned this AREA request into the 2x2-tap kernel's integer tile BEFORE its staging was known to fit; a request that does not fit
         // (not reachable with the default 40 KiB budget at 3 : 2 / 2 : 1, but a smaller TSVPP_LDS_KB gets there) would fall through to the gather kernel with
@@ -602,7 +608,7 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
         return launch_fused(mode_in, out, vec, again, t, stream, info);
     }
     if (!staged) d.dma = 0;
-    sel_bicubic_cols(mode, vec, bc_r32, d, S, stream, info);
+    sel_bicubic_cols(mode, out, vec, stream_r32, d, S, stream, info);
     const size_t bc_lds = lds_bytes;
     if (mode == M_NONE && vec && d.in_aligned4 && !d.force_gather) staged = true; // colour-only fast path
     // ... and for the outputs that are the planes themselves (uint8 Y800 / NV12) a copy of 16 bytes per lane (vpp_copy16_kernel)

@@ -10,6 +10,8 @@ LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "lib", "libtsvpp.so"))
 
 TSVPP_MAX_BATCH = 128
 TSVPP_OPT_INPUTS_READY = 1
+TSVPP_OPT_COLOR_G_TERM = 2
+TSVPP_OPT_UNSAFE_COEFFS = 3
 
 
 class NV12(ctypes.Structure):

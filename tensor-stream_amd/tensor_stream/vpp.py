@@ -13,6 +13,8 @@ from . import _native as N
 
 
 OPT_INPUTS_READY = N.TSVPP_OPT_INPUTS_READY
+OPT_COLOR_G_TERM = N.TSVPP_OPT_COLOR_G_TERM
+OPT_UNSAFE_COEFFS = N.TSVPP_OPT_UNSAFE_COEFFS
 
 
 class FourCC(Enum):  # reference tensor_stream/tensor_stream.py:48-62
@@ -247,7 +249,7 @@ class VideoProcessor:
         self._tables.append(h)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         N.check(self._lib.tsvpp_table_set(h, 0, n, frames, outs, stream))
-        return {"n": n, "handle": h, "params": p, "out": out, "keep": (ys, uvs)}
+        return {"n": n, "handle": h, "params": p, "out": out, "keep": (ys, uvs), "width": frames[0].width}
 
     def run_table(self, table, first=0, n=None, params=None, stream=None):
         """Converts entries [first, first + n) of a table made by make_table (default: all of it, with the parameters it was made with)."""
@@ -255,6 +257,15 @@ class VideoProcessor:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         p = table["params"] if params is None else (params.parameters if isinstance(params, FrameParameters) else params)
         cnt = table["n"] - first if n is None else n
+        if params is not None:
+            #  the table's output tensors were allocated for the parameters it was made with and their addresses live in the device table: other
+            # parameters are fine only while every frame still fits its registered output
+            y0 = table["keep"][0][0]
+            w = table.get("width") or y0.shape[1]
+            need = int(self._lib.tsvpp_out_bytes(ctypes.byref(p), int(w), int(y0.shape[0])))
+            have = table["out"][0].numel() * table["out"].element_size()
+            if need == 0 or need > have:
+                raise RuntimeError(f"-3: run_table(params=...) needs {need} bytes per frame, the table's outputs hold {have}")
         N.check(self._lib.tsvpp_convert_table(self._ctx, table["handle"], first, cnt, ctypes.byref(p), stream))
         return table["out"]
 

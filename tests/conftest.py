@@ -10,6 +10,10 @@ for p in (ROOT, os.path.join(ROOT, "tensor-stream_amd"), os.path.join(ROOT, "tes
         sys.path.insert(0, p)
 
 
+# The tests drive the library's A/B knobs (TSVPP_GEO, TSVPP_R32, ...): those are honoured only under this gate (tsvpp_api.cpp: read_env_knobs)
+os.environ.setdefault("TSVPP_DEBUG_KNOBS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

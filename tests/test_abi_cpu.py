@@ -215,3 +215,33 @@ def test_cpp_mirror_exports_the_reference_class_and_stage_launchers():
                    "VideoProcessor::Init(", "VideoProcessor::Convert(AVFrame*, AVFrame*, FrameParameters&, std::", "VideoProcessor::DumpFrame<",
                    "VideoProcessor::Close()", "channelsByFourCC(FourCC)"):
         assert needle in syms, needle
+
+
+def test_debug_knobs_are_honoured_only_under_the_gate():
+    """the 25 TSVPP_* A/B knobs act only under TSVPP_DEBUG_KNOBS=1; without the gate a set knob is reported once on stderr and ignored.
+    tsvpp_describe runs the same read_env_knobs as tsvpp_create: observable without a GPU."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import tensor_stream as ts; "
+            "print(ts.describe(ts.FrameParameters(width=1280, height=720, resize_type=1, pixel_format=2, planes_pos=0, normalization=True), 1920, 1080, pitch=2048)['kernel'])"
+            % os.path.join(ROOT, "tensor-stream_amd"))
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TSVPP_")}
+        env.update(env_extra)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+        assert p.returncode == 0, p.stderr[-400:]
+        return p.stdout.strip(), p.stderr
+    base, err = run({})
+    assert "vpp_bilinear_kernel" in base and "tsvpp:" not in err
+    ignored, err = run({"TSVPP_FORCE_GATHER": "1"})
+    assert ignored == base and "ignoring TSVPP_FORCE_GATHER=1" in err
+    forced, err = run({"TSVPP_FORCE_GATHER": "1", "TSVPP_DEBUG_KNOBS": "1"})
+    assert forced != base and "gather" in forced
+
+
+def test_adapter_compiles_against_a_libavutil_frame_header():
+    """the TSVPP_HAVE_LIBAV branch of cpp/VideoProcessor.h (AVFrame from <libavutil/frame.h>) goes through hipcc -- against a vendored
+    compile-check declaration (cpp/compat/libavutil/frame.h), objects only."""
+    import subprocess
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "tensor-stream_amd", "cpp"), "libav-check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "libav-check ok" in p.stdout, (p.stdout[-300:], p.stderr[-600:])

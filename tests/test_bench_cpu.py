@@ -122,7 +122,9 @@ def test_gpus_2_self_spawn_on_gloo():
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["per_rank"]["min_frames_per_s"] <= res["per_rank"]["max_frames_per_s"]
     assert abs(res["value"] - 2 * 64 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3  # whole-job aggregate
-    assert "cpu_baseline" not in res  # rank 0 at N = 1 only
+    # (round 6) N > 1 lines carry the CPU baseline too (rank 0, after the timed regions) and every rank's own roofline fraction
+    assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] == "port"
+    assert len(res["per_rank"]["roofline_frac"]) == 2 and all(x > 0 for x in res["per_rank"]["roofline_frac"])
 
 
 def test_gpus_more_than_visible_prints_not_measured():
@@ -232,7 +234,26 @@ def test_gpus_8_self_spawn_on_gloo():
     assert abs(res["value"] - 8 * 64 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3
     ow = res["config"]["other_workloads"]
     assert set(ow) == {"c1", "c2", "c3", "c4", "c5"} and all(ow[k]["frames_per_s"] > 0 for k in ow)
-    assert "cpu_baseline" not in res
+    assert res["cpu_baseline"]["value"] > 0 and len(pr["roofline_frac"]) == 8
+
+
+def test_c5_as_baseline_words_it_64_named_consumers_over_8_ranks_on_gloo():
+    """`--workload c5 --consumers 64 --gpus 8` -- 64 NAMED consumers, eight per rank, each rank its own converter; rehearsed at world 8 on gloo with
+    the stub engine: one line, the consumer sharding in it, the aggregate = 64 conversions per step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSVPP_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--workload", "c5", "--consumers", "64",
+                        "--cpu-budget", "0.05"], env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _line(p.stdout)
+    c = res["config"]["consumers"]
+    assert res["n_gpus"] == 8 and c["total"] == 64 and c["per_rank"] == 8 and c["names_rank0"] == ["consumer0", "consumer7"]
+    assert res["config"]["frames_per_step"] == 8 and abs(res["value"] - 8 * 8 * 4 / (res["ms_per_step"] * 4e-3)) / res["value"] < 1e-3
+    assert len(res["per_rank"]["frames_per_s"]) == 8 and "other_workloads" not in res["config"]
+    # a consumer count the ranks cannot share evenly is a set-up error, reported as ONE error line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0", "--workload", "c5", "--consumers", "60"],
+                       env=dict(env, TSVPP_BENCH_SETUP_TIMEOUT="20"), capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0 and '{"metric"' not in p.stdout and "not a multiple of the world size" in p.stdout
 
 
 def test_torchrun_world1_takes_the_collective_path_on_gloo():

@@ -9,6 +9,7 @@ import subprocess
 import sys
 
 import pytest
+from util import knob_run
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -48,7 +49,7 @@ def _check(p):
     assert cb["collective"] == "torch.distributed.broadcast" and cb["backend"] == "nccl" and cb["device"].startswith("cuda") and cb["world"] == 1
     rf = res["roofline"]
     assert rf["kernel"].startswith("tsvpp::") and "*" not in rf["kernel"]   # the dispatched kernel's name, not a wildcard
-    knobs = any(k.startswith("TSVPP_") for k in os.environ)                  # (knob runs, tools/knob_matrix.sh, dispatch other -- slower -- kernels)
+    knobs = knob_run()                  # (knob runs, tools/knob_matrix.sh, dispatch other -- slower -- kernels)
     if not knobs:
         assert rf["kernel"].startswith("tsvpp::vpp_bilinear_kernel")
     # Perf floors ("0.2 < frac" let a threshold slip that halves the headline pass): ~92 % of what the driver measured in round 4 /
@@ -81,7 +82,7 @@ def test_force_dist_world1_nccl():
     _check(p)
 
 
-@pytest.mark.skipif(any(k.startswith("TSVPP_") for k in os.environ), reason="knob runs dispatch other kernels on purpose")
+@pytest.mark.skipif(knob_run(), reason="knob runs dispatch other kernels on purpose")
 @pytest.mark.parametrize("wl,key", [("c3", "c3_fps"), ("c2", "c2")])
 def test_perf_floors_of_the_other_baseline_configurations(wl, key):
     """C3 (512-frame launches out of a persistent frame table on the row-segment kernel: 3.25 M frames/s, 0.72 of the roofline on moved bytes; the byte-gather
@@ -108,3 +109,16 @@ def test_single_frame_latency_tool():
         assert res[k] is not None and 0 < res[k]["min"] <= res[k]["p50"] <= res[k]["p99"], (k, res)
     assert res["convert_into_us"]["p50"] < 3000   # the reference accepts 3 +- 3 ms for getFrame; one launch + a stream sync is tens of microseconds
     print("\n" + json.dumps(res))
+
+
+def test_c5_named_consumers_through_the_facade_world1():
+    """`--workload c5 --consumers 16` (C5 as BASELINE words it, here 16 named consumers on the one GPU of this box): the timed step is one
+    TensorStreamConverter.read_many over this rank's consumers; the line names the sharding and its parity check."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--consumers", "16", "--steps", "20", "--warmup", "5", "--cpu-budget", "2"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    c = res["config"]["consumers"]
+    assert c["total"] == 16 and c["per_rank"] == 16 and res["config"]["frames_per_step"] == 16
+    assert res["config"]["parity"].startswith("bit-exact") and res["value"] > 0 and res["cpu_baseline"]["value"] > 0
+    print("\n" + json.dumps({k: res[k] for k in ("value", "ms_per_step", "roofline")}))

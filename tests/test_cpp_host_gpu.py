@@ -42,5 +42,7 @@ def test_cpp_videoprocessor_convert(tmp_path, oracle, case):
     assert tok[0] == "ok" and (int(tok[1]), int(tok[2])) == (ow, oh)
     # consumer pool of 2: second name accepted, third refused with VREADER_ERROR; input frame was unref'ed
     assert "second=0" in r.stdout and "third=-3" in r.stdout and "input_unref=1" in r.stdout
+    # VideoProcessor::Release (round 6): the result handed back is reused by the next Convert of that size, same bytes; foreign / double releases are refused
+    assert all(t in r.stdout for t in ("release=0", "reuse=1", "same=1", "foreign=-3", "twice=-3", "again=0")), r.stdout
     got = np.fromfile(out, dtype=np.uint8)
     assert np.array_equal(got, ref.view(np.uint8))

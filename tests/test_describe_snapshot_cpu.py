@@ -17,7 +17,7 @@ def _maker():
     return m
 
 
-@pytest.mark.skipif(any(k.startswith("TSVPP_") for k in os.environ), reason="knob runs select other kernels on purpose")
+@pytest.mark.skipif(any(k.startswith("TSVPP_") and k not in ("TSVPP_DEBUG_KNOBS", "TSVPP_BENCH_STUB") for k in os.environ), reason="knob runs select other kernels on purpose")
 def test_selection_matches_the_committed_snapshot():
     m = _maker()
     want = json.load(open(os.path.join(HERE, "golden", "describe_snapshot.json")))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 AREA = 3
@@ -40,7 +40,7 @@ def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 
 ])
 def test_wide_ratios(vpp, oracle, src, dst, kernel):
     import tensor_stream as ts
-    if not any(k.startswith("TSVPP_") for k in os.environ):   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
+    if not knob_run():   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
         p = ts.describe(ts.FrameParameters(width=dst[0], height=dst[1], resize_type=AREA, normalization=True, planes_pos=0), src[0], src[1])
         assert p["kernel"].startswith(kernel), p
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 
     import tensor_stream as ts
     fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=BICUBIC, pixel_format=fourcc, planes_pos=planes,
                             normalization=norm)
-    if expect_int is not None and not any(k.startswith("TSVPP_") for k in os.environ):  # knob runs (tools/knob_matrix.sh) pick other kernels
+    if expect_int is not None and not knob_run():  # knob runs (tools/knob_matrix.sh) pick other kernels
         k = ts.describe(fp, w, y.shape[0], pitch=y.shape[1])["kernel"]
         # (exactly 3 : 2 / 2 : 1 on dword-aligned planes: the streaming integer kernel of vpp_bicubic_r32.hip, tests/test_gpu_bicubic_r32.py)
         assert (k.startswith("vpp_bicubic_int_kernel") or k.startswith("vpp_bicubic_r32_kernel")) == expect_int, k

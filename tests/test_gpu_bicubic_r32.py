@@ -8,12 +8,12 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 
 BICUBIC = 2
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)  # knob runs (tools/knob_matrix.sh) pick other kernels
+KNOBS = knob_run()  # knob runs (tools/knob_matrix.sh) pick other kernels
 
 
 def run(vpp, oracle, y, uv, w, dst, fourcc=2, planes=0, norm=False, crop=(0, 0, 0, 0), expect=True):

@@ -11,13 +11,13 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 
 BILINEAR = 1
 WX0, TWO = "vpp_bilinear_rows_kernel<OUT,wx0>", "vpp_bilinear_rows_kernel<OUT,2x2>"
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)  # knob runs (tools/knob_matrix.sh) pick other kernels on purpose
+KNOBS = knob_run()  # knob runs (tools/knob_matrix.sh) pick other kernels on purpose
 
 
 def run(vpp, oracle, y, uv, w, dst, fourcc=1, planes=0, norm=True, crop=(0, 0, 0, 0), expect=None):

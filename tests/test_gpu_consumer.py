@@ -100,6 +100,10 @@ def test_replay_is_invalidated_by_coefficients_and_options(oracle):
     k = v.get_coeffs()
     k2 = list(k)
     k2[0] = 1.0  # y_scale
+    from tensor_stream import vpp as V
+    with pytest.raises(RuntimeError):
+        v.set_coeffs(k2)  # a block that differs from the reference's literals needs TSVPP_OPT_UNSAFE_COEFFS
+    v.set_option(V.OPT_UNSAFE_COEFFS, 1)
     v.set_coeffs(k2)
     b = v.Convert(y, uv, fp).cpu().numpy().ravel()
     v.set_coeffs(k)

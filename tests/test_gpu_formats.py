@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12, ulp_diff
+from util import synth_nv12, ulp_diff, knob_run
 
 pytestmark = pytest.mark.gpu
 Y800, RGB24, BGR24, NV12, UYVY, YUV444, HSV = range(7)
@@ -164,7 +164,7 @@ def test_plane_copies_16_bytes_per_lane(vpp, oracle, fcc):
         fp = ts.FrameParameters(crop_coords=crop, pixel_format=fcc, normalization=False)
         cw, ch = (crop[2] - crop[0], crop[3] - crop[1]) if crop[2] else (w, h)
         want16 = cw % 16 == 0 and ch % 4 == 0 and pitch % 4 == 0 and crop[0] % 4 == 0
-        if not any(e.startswith("TSVPP_") for e in os.environ):  # (knob runs, tools/knob_matrix.sh, select other kernels on purpose)
+        if not knob_run():  # (knob runs, tools/knob_matrix.sh, select other kernels on purpose)
             k = ts.describe(fp, w, h, pitch=pitch, n_frames=1)["kernel"]
             assert k.startswith("vpp_copy16_kernel") == want16, (k, w, h, pitch, crop)
         got = run(vpp, y, uv, fcc, False, crop=crop, width=w)

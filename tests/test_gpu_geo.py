@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 BILINEAR, AREA = 1, 3
@@ -52,7 +52,7 @@ def check(v, oracle, y, uv, w, dst, n=1, geo=1, **kw):
     h = y.shape[0]
     crop = kw.get("crop", (0, 0, 0, 0))
     # the request takes the geometry tables (host logic; the crop must not change the pitch)
-    if not any(k.startswith("TSVPP_") for k in os.environ):   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
+    if not knob_run():   # (tools/knob_matrix*.sh replay the suite under knobs that change the selection)
         with _Env(TSVPP_GEO="2", TSVPP_R32="0"):
             d = V.describe(fp, w, h, pitch=y.shape[1], n_frames=n)
             # (a width 4 k + 2 ends in a shifted tile column -- tail == 2 -- and the tables' column records are per aligned quad: no tables there)

@@ -347,3 +347,27 @@ def test_bilinear_with_one_axis_of_zero_weights(vpp, oracle, src, dst, planes, n
     """Odd integer ratio on ONE axis: the samplers do not fetch the taps a zero weight multiplies (LaunchDesc::wx_zero / wy_zero) -- same bits."""
     y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[1])
     check(vpp, oracle, y, uv, dst=dst, resize_type=BILINEAR, fourcc=RGB24, planes=planes, normalization=norm)
+
+
+@pytest.mark.parametrize("g_term,bits", [(1, 0), (2, 2048)])
+def test_colour_g_term_variants_over_all_2pow24_triples(oracle, g_term, bits):
+    """TSVPP_OPT_COLOR_G_TERM: the other two operation trees of the green chroma term, for holders of goldens of the real reference binary -- every
+    (Y, U, V) triple against the oracle's matching contraction variant, through the LDS colour kernel (planar uint8) and the streaming output side (merged)."""
+    import tensor_stream as ts
+    from tensor_stream import vpp as V
+    CT_RESIZE, CT_INNER = 1 | 2 | 8 | 16 | 64, 256
+    v = ts.VideoProcessor(device=0)
+    v.set_option(V.OPT_COLOR_G_TERM, g_term)
+    assert v.get_option(V.OPT_COLOR_G_TERM) == g_term
+    y, uv = coverage_frame()
+    oracle.set_contract(CT_RESIZE | CT_INNER | bits)
+    try:
+        check(v, oracle, y, uv, fourcc=RGB24, planes=PLANAR, normalization=False)
+        # ... and behind a resize whose streaming kernel ends in vpp_r32_store.h's colour stage
+        ys, uvs = synth_nv12(1920, 1080, seed=31 + g_term)
+        check(v, oracle, ys, uvs, dst=(1280, 720), resize_type=BILINEAR, fourcc=BGR24, planes=MERGED, normalization=False)
+    finally:
+        oracle.set_contract(-1)
+    v.set_option(V.OPT_COLOR_G_TERM, 0)
+    check(v, oracle, ys, uvs, dst=(1280, 720), resize_type=BILINEAR, fourcc=BGR24, planes=MERGED, normalization=False)
+    v.Close()

@@ -8,10 +8,10 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)
+KNOBS = knob_run()
 NEAREST, BILINEAR, BICUBIC = 0, 1, 2
 
 

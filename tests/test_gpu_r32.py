@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 NEAREST, BILINEAR, AREA = 0, 1, 3
@@ -18,7 +18,7 @@ def check(vpp, oracle, y, uv, w, dst, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0),
     import tensor_stream as ts
     from tensor_stream import vpp as V
     fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
-    if not any(k.startswith("TSVPP_") for k in os.environ):
+    if not knob_run():
         k = V.describe(fp, w, y.shape[0], pitch=y.shape[1], n_frames=n)["kernel"]
         assert k.startswith("vpp_bilinear_r32_kernel") == r32, (k, w, y.shape, dst, crop)
         if r32:
@@ -92,7 +92,7 @@ def test_r32_uyvy_yuv444_in_one_pass(vpp, oracle, src, pitch, rt, ratio, fmt):
         pytest.skip("not a size of the streaming kernel")
     y, uv = synth_nv12(w, h, seed=w + rt + ratio[0], pitch=pitch)
     fp = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=rt, pixel_format=fmt, planes_pos=1, normalization=False)
-    if not any(k.startswith("TSVPP_") for k in os.environ):
+    if not knob_run():
         dsc = V.describe(fp, w, h, pitch=pitch)
         assert dsc["out"] == ("uyvy_u8" if fmt == UYVY else "yuv444_u8") and dsc["kernel"].startswith("vpp_bilinear_r32_kernel") and "pass2" not in dsc, dsc
     check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt)

@@ -7,12 +7,12 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 NEAREST, BILINEAR, BICUBIC, AREA = 0, 1, 2, 3
 Y800, RGB24, BGR24, NV12, UYVY, YUV444, HSV = 0, 1, 2, 3, 4, 5, 6
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)
+KNOBS = knob_run()
 
 
 def check(vpp, oracle, y, uv, w, rt, fourcc=RGB24, planes=0, crop=(0, 0, 0, 0), n=1, rep2=True, norm=False, knob_ctx=False):

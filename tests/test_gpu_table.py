@@ -181,3 +181,79 @@ def test_a_table_conversion_is_hip_graph_capturable_and_replays_the_table_as_it_
         assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), (f, src)
     del g
     vpp.free_table(tab)
+
+
+def test_table_set_twice_before_the_first_upload_ran_keeps_stream_order(vpp, oracle):
+    """every upload is staged in its own pinned slot.  The stream is kept busy (a long device-side sleep) while the SAME entries are set twice
+    with a conversion behind each: the first conversion must run with the first set's pointers (until round 5 both uploads were copied out of one pinned mirror
+    that the second call had already rewritten)."""
+    import tensor_stream as ts
+    w, h, n = 640, 360, 8
+    ysA, uvsA = _pool(w, h, w, n, seed=91)
+    ysB, uvsB = _pool(w, h, w, n, seed=92)
+    fp = ts.FrameParameters(width=320, height=180, resize_type=1, pixel_format=1, planes_pos=1, normalization=False)
+    outA = vpp._alloc(fp.parameters, w, h, n)
+    outB = vpp._alloc(fp.parameters, w, h, n)
+    outA.zero_()
+    outB.zero_()
+    tab = vpp.make_table(ysA, uvsA, fp, out=outA, width=w)
+    torch.cuda.synchronize()
+    lib, N = vpp._lib, __import__("tensor_stream")._native
+    s = torch.cuda.Stream()
+
+    def arrays(ys, uvs, out):
+        fr = (N.NV12 * n)(*[vpp._frame(ys[i], uvs[i], w, None) for i in range(n)])
+        outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        return fr, outs
+
+    with torch.cuda.stream(s):
+        torch.cuda._sleep(200_000_000)  # ~0.1 s of device time: everything below queues up behind it
+        for rnd in range(3):            # more uploads in flight than a naive double buffer would hold
+            for ys, uvs, out in ((ysA, uvsA, outA), (ysB, uvsB, outB)):
+                fr, outs = arrays(ys, uvs, out)
+                N.check(lib.tsvpp_table_set(tab["handle"], 0, n, fr, outs, s.cuda_stream))
+                N.check(lib.tsvpp_convert_table(vpp._ctx, tab["handle"], 0, n, ctypes.byref(fp.parameters), s.cuda_stream))
+    s.synchronize()
+    for f in (0, n - 1):
+        _check(oracle, ysA, uvsA, outA, f, w, (0, 0, 0, 0), (320, 180), 1, 1, 1, False)
+        _check(oracle, ysB, uvsB, outB, f, w, (0, 0, 0, 0), (320, 180), 1, 1, 1, False)
+    vpp.free_table(tab)
+
+
+def test_run_table_with_other_parameters_checks_the_registered_outputs(vpp):
+    """the outputs a table registered were sized for the parameters it was made with."""
+    import tensor_stream as ts
+    w, h, n = 640, 360, 4
+    ys, uvs = _pool(w, h, w, n, seed=93)
+    fp = ts.FrameParameters(width=320, height=180, resize_type=1, pixel_format=1, planes_pos=1, normalization=False)
+    tab = vpp.make_table(ys, uvs, fp, width=w)
+    vpp.run_table(tab)
+    vpp.run_table(tab, params=ts.FrameParameters(width=320, height=180, resize_type=0, pixel_format=2, planes_pos=0, normalization=False))  # same size: fine
+    vpp.run_table(tab, params=ts.FrameParameters(width=160, height=90, resize_type=1, pixel_format=1, planes_pos=1, normalization=False))   # smaller: fine
+    for bad in (ts.FrameParameters(width=640, height=360, pixel_format=1), ts.FrameParameters(width=320, height=180, resize_type=1, pixel_format=1, normalization=True)):
+        with pytest.raises(RuntimeError):
+            vpp.run_table(tab, params=bad)
+    torch.cuda.synchronize()
+    vpp.free_table(tab)
+
+
+def test_context_destroyed_before_its_table():
+    """tsvpp_destroy releases the device memory of live tables; their handles stay valid for tsvpp_table_destroy (and for nothing else)."""
+    import tensor_stream as ts
+    from tensor_stream import _native as N
+    v = ts.VideoProcessor(device=0)
+    w, h, n = 320, 180, 2
+    ys, uvs = _pool(w, h, w, n, seed=94)
+    fp = ts.FrameParameters(pixel_format=1)
+    tab = v.make_table(ys, uvs, fp, width=w)
+    v.run_table(tab)
+    torch.cuda.synchronize()
+    handle, ctx = tab["handle"], v._ctx
+    v._tables = []          # (Close would destroy the table first: take it away)
+    lib = N.lib()
+    lib.tsvpp_destroy(ctx)
+    v._ctx = ctypes.c_void_p()
+    fr = (N.NV12 * n)(*[v._frame(ys[i], uvs[i], w, None) for i in range(n)])
+    outs = (ctypes.c_void_p * n)(*[tab["out"][i].data_ptr() for i in range(n)])
+    assert lib.tsvpp_table_set(handle, 0, n, fr, outs, None) == -3   # orphaned: VREADER_ERROR, no crash
+    lib.tsvpp_table_destroy(handle)

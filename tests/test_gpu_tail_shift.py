@@ -8,11 +8,11 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 NEAREST, BILINEAR, BICUBIC, AREA = 0, 1, 2, 3
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)
+KNOBS = knob_run()
 
 
 def check(vpp, oracle, y, uv, w, dst, rt, fourcc=2, planes=0, norm=True, crop=(0, 0, 0, 0), n=1, tail=2, kernel=None):

@@ -7,11 +7,11 @@ import numpy as np
 import pytest
 import torch
 
-from util import synth_nv12
+from util import synth_nv12, knob_run
 
 pytestmark = pytest.mark.gpu
 NEAREST, BILINEAR, AREA = 0, 1, 3
-KNOBS = any(k.startswith("TSVPP_") for k in os.environ)
+KNOBS = knob_run()
 
 
 def check(vpp, oracle, y, uv, w, dst, rt, fourcc=2, planes=0, norm=True, crop=(0, 0, 0, 0), n=1, expect=True):
@@ -76,7 +76,7 @@ def test_a_tile_that_cannot_be_staged_runs_as_the_area_request_it_is(oracle, mon
     try:
         y, uv = synth_nv12(1920, 1080, seed=44, pitch=2048)
         fp = ts.FrameParameters(width=1280, height=720, resize_type=AREA, pixel_format=2, planes_pos=0, normalization=True)
-        if not any(k.startswith("TSVPP_") and k != "TSVPP_LDS_KB" for k in os.environ):  # (knob runs route the request elsewhere on purpose)
+        if not knob_run(("TSVPP_LDS_KB",)):  # (knob runs route the request elsewhere on purpose)
             assert ts.describe(fp, 1920, 1080, pitch=2048)["kernel"].startswith("vpp_fused_gather_kernel")  # (describe reads the same knob)
         got = v.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=1920)
         torch.cuda.synchronize()

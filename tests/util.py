@@ -1,5 +1,14 @@
 """Shared helpers for the parity tests (test infrastructure)."""
+import os
+
 import numpy as np
+
+
+def knob_run(allowed=()):
+    """Is the suite being replayed under A/B knobs (tools/knob_matrix*.sh)?  Then tests that name the kernel a request must take stand down.  The gate itself
+    (TSVPP_DEBUG_KNOBS, set by tests/conftest.py so that tests CAN use knobs) and the bench.py test switches are not knobs."""
+    skip = {"TSVPP_DEBUG_KNOBS"} | set(allowed)
+    return any(k.startswith("TSVPP_") and not k.startswith("TSVPP_BENCH_") and k not in skip for k in os.environ)
 
 
 def synth_nv12(w, h, seed, pitch=None):

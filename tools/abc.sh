@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # same-box A/B of environment settings over ad-hoc workloads:
 #   tools/abc.sh "SRC:DST:RESIZE:FOURCC:PLANES:NORM ..." "ENV_A" "ENV_B" ...     (an empty ENV = defaults)
 # prints one row per workload, one column per setting: frames/s, fraction of the 8 TB/s roofline, parity

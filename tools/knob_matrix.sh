@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Runs the whole GPU parity suite once per tuning-knob setting: every alternative code path (gather fallbacks, compact vs LDS-DMA staging, the
 # BICUBIC kernels (integer / wave-per-tile with every staging mode and tile height / gathers), generic vs table vs streaming AREA kernels, thread-tile
 # heights, direct-kernel thresholds, workgroup shapes, tile orders, store policies, geometry tables, the streaming 3:2 / 2:1 kernel incl. its

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # perf matrix over common conversions (looking for cliffs): tools/matrix.sh
 for c in "1920x1080:224x224" "1920x1080:640x640" "1920x1080:960x540" "1920x1080:1920x1080" "1280x720:1920x1080" "3840x2160:1920x1080" "1080x608:480x360" "1920x1080:300x300" "1920x1080:1280x720" "1920x1080:1440x810"; do
   for r in NEAREST BILINEAR BICUBIC AREA; do

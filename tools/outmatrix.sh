@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Output-flavour matrix on the headline geometry (1080p -> 720p BILINEAR), colour-only 1080p, and -- round 4 -- BICUBIC at 1080p -> 720p (the streaming
 # kernel) and 720p -> 1080p (the column kernel).  Sparse samplers print the ROI-formula fraction (roi) next to the fraction on the bytes they move.
 row() { # geometry resize fourcc planes norm

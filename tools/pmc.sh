@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # PMC passes (each in its own run, kernel-trace only) of one bench.py workload under an environment setting:
 #   tools/pmc.sh <tag> "<ENV=...>" [bench.py args...]   -> gpurun_out/pmc_<tag>.txt (means per dispatch of the tsvpp kernel)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Profiles one bench.py workload with rocprofv3 on the GPU box (run through gpurun).
 #   tools/profile.sh <tag> [bench.py args...]
 # Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2-4: PMC counters, each in its own run

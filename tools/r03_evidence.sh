@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Round-3 evidence: rocprofv3 kernel-trace + PMC passes of every bench workload on ONE box, one commit (run through gpurun):
 #   tools/r03_evidence.sh        -> gpurun_out/prof_<tag>/, then tools/save_profile.sh r03 <tag> copies the summaries into profiles/
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

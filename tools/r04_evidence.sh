@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # What produced profiles/r04_* (each block is one gpurun call; run from the repo root on the GPU box, copy gpurun_out/* into profiles/ afterwards).
 # 1. the suite, the rocprofv3 passes of the final kernels, the bench lines, the matrices
 python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/r04_gpu_suite.txt

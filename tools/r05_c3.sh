@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call 1: the row-segment BILINEAR kernel (vpp_bilinear_rows.hip) -- its tests, then same-box A/B against the byte-gather kernel it replaces
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 python -m pytest tests/test_gpu_bilinear_rows.py -x -q 2>&1 | tail -15 > gpurun_out/r05_rows_tests.txt
 line() { python -c "
 import sys,json

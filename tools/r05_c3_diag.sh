@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: where does C3's launch spend its time?  --alias 1 = reads from cache, 2 = writes stay in cache, 3 = both
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 python -m pytest tests/test_gpu_bilinear_rows.py -x -q 2>&1 | tail -5 > gpurun_out/r05_rows_tests.txt
 line() { python -c "
 import sys,json

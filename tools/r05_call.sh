@@ -1,5 +1,5 @@
 #!/bin/bash
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 line() { python -c "
 import sys,json
 try:

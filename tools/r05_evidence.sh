@@ -3,7 +3,7 @@
 #   for w in headline c1 c2 c3 c4 c5 area bicubic bicubic_u8m up2_u8m; do bash tools/save_profile.sh r05 $w; done   and copy gpurun_out/r05_* into profiles/).
 # The same-box A/B files of the round (r05_rows_ab, r05_c3_diag, r05_table_ab, r05_point_rn_ab, r05_c4_shapes, r05_c4_diag, r05_rep2_ab, r05_up2_shapes, r05_bicubic_cols_u8_ab,
 # r05_prn_nt_variants, r05_u8_nt_ab, r05_u8_sc1_ab, r05_st1_nt_variants, r05_knob_matrix_streaming) were written by the tools/r05_call.sh of their commit (see git log).
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 case "$1" in
 1)  # the suite, the rocprofv3 passes of the final kernels, the bench lines
     python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/r05_gpu_suite.txt

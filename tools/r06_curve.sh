@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, first contact with the small-launch regime: the GPU suite, the launch curve (1 .. 64 frames per launch) of the headline / C3 / C4 with and without
 # TSVPP_OPT_INPUTS_READY, other consumer shapes, and workgroup shapes at small n.  gpurun --timeout 1500 -- bash tools/r06_curve.sh
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 O=gpurun_out/r06
 mkdir -p $O
 export TMPDIR=/tmp

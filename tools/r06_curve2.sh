@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, second pass on the small-launch regime: host cost of a launch, honest pools (reads > 3x the Infinity Cache), the consumer pool with and without
 # TSVPP_OPT_INPUTS_READY, and the two effects of the option (second stream / no barrier bit) apart.  gpurun --timeout 1500 -- bash tools/r06_curve2.sh
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 O=gpurun_out/r06
 mkdir -p $O
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, third pass: replay cache + pinned issuing threads + size rule; A/B of the option's values (1 both, 2 barrier-free only, 3 second stream only).
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 O=gpurun_out/r06
 mkdir -p $O
 export TMPDIR=/tmp

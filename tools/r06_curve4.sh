@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, fourth pass: final thresholds, facade batch reads, vpp_latency on a rotating ring + graph8, rocprofv3 kernel traces of the n = 1 and n = 8 launches.
-cd ${GRAFT_REPO_ROOT:-.}
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
 R=$PWD
 O=$R/gpurun_out/r06
 mkdir -p $O

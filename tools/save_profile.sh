@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Copies the judged summaries of gpurun_out/prof_<tag>/ into profiles/<round>_<tag>_*: tools/save_profile.sh r01 headline
 R=$1; T=$2; S=gpurun_out/prof_$T; D=profiles
 head -4 $S/kt/kt_kernel_stats.csv > $D/${R}_${T}_kernel_stats.csv

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # DIAGNOSTIC: what launches of independent batches on 1 / 2 / 3 consumer streams do to throughput (bench.py --streams N: steps issued round-robin, one
 # launch's drain overlaps the next one's fill).  The bench line itself times ONE stream; this is the caller-side lever of DESIGN.md section 8 "Launch size".
 one() { python bench.py $1 --streams $2 --steps 24 --warmup 3 --no-cpu-baseline --no-others 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); rf=r['roofline']; print('  streams=$2 %9.0f fps  step %.4f ms  %s' % (r['value'], r['ms_per_step'], r['config']['parity'][:9]), end='')"; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # Outputs 4 k + 2 columns wide (854x480, 1366x768, 270x270) next to their 4 k neighbours, per resize type: shift=0 -- the two-column tail launch behind the
 # main launch (rounds 1-3, TSVPP_TAIL_SHIFT=0); shift=1 -- the launch's last tile column shifted to the frame's right edge, no second launch (default)
 # (ms_per_step covers every launch of a step; frac(step) = algorithmic bytes of a step / ms_per_step / 8 TB/s)

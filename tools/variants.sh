@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSVPP_DEBUG_KNOBS=1  # the A/B knobs are honoured only under this gate (round 6)
 # same-box A/B of library BUILDS (variants/<name>.so, built here with different -D flags) over ad-hoc workloads:
 #   tools/variants.sh "SRC:DST:RESIZE:FOURCC:PLANES:NORM ..." "ENV" A B C ...
 # each variant is copied over tensor-stream_amd/lib/libtsvpp.so on the GPU box (a scratch copy of the tree) before its runs
