@@ -22,15 +22,32 @@
 // No workgroup barrier: a wave's LDS operations execute in order and nothing is shared between waves.  Rows are staged in PAIRS per output row even
 // when two output rows share a source row (vertical ratios below 2): the kernel is selected for ratio products >= 12 (launch_fused), where that
 // is rare; it stays correct for any ratio whose segment fits one instruction (L <= 64, horizontal ratios up to ~15.7).
+//   POINT    (round 6) the pure point samplers -- NEAREST (src/Resize.cu:242-267), BILINEAR / BICUBIC requests whose weights are all zero -- on the same front
+//            end: ONE segment per output row (R luma + R / 2 chroma segments), the sample is a byte read.  Until round 6 they ran on vpp_point_kernel, which stages
+//            one LDS row per output row per WORKGROUP tile behind a barrier: 1080p -> 224 x 224 NEAREST moved 0.51 of the roofline at 512 frames per launch where
+//            BILINEAR, with twice the rows to fetch, moved 0.71 on this kernel (profiles/r06_nn_matrix.txt).
 #include "vpp_device.h"
 
 #pragma clang fp contract(off)
 
 namespace tsvpp {
 
-template <int OUT, bool WX0>
+// source coordinate of one output index for the variants of this kernel: the 2x2-tap ones and the zero-weight point samplers share bilinear_axis's (BICUBIC's
+// coordinate is the same fused expression, vpp_axis.h), NEAREST has its own
+template <bool NEAR> __device__ __forceinline__ int rows_coord(int idx, float ratio, int limit) {
+    if constexpr (NEAR) return point_coord<PK_NEAREST>(idx, ratio, limit);
+    int p;
+    float w_;
+    bilinear_axis(idx, ratio, limit, p, w_);
+    return p;
+}
+
+enum { BRK_2X2 = 0, BRK_WX0 = 1, BRK_POINT = 2, BRK_NEAREST = 3 }; // (BRK_POINT: zero-weight BILINEAR / BICUBIC, bilinear_axis coordinates; BRK_NEAREST: (int)(r j))
+template <int OUT, int KIND>
 __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const LaunchDesc d, const FrameTable t) {
     using T = typename OutT<OUT>::type;
+    constexpr bool WX0 = KIND == BRK_WX0, POINT = KIND >= BRK_POINT, NEAR = KIND == BRK_NEAREST;
+    constexpr int SPR = POINT ? 1 : 2; // staged segments per output row
     const TileId id = decode_tile(d);
     if (!id.valid) return;
     const int lane = (int)(threadIdx.x & 63u), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -42,12 +59,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
     const int ch = d.src_h >> 1;
 
     // the tile's byte columns: luma [x_lo, x(j_last) + 1], chroma [2 cx_lo, 2 cx(cj_last) + 3] -- the host sized L for both
-    int x_lo, cx_lo;
-    {
-        float w_;
-        bilinear_axis(j_first, d.xr, d.src_w, x_lo, w_);
-        bilinear_axis(j_first >> 1, d.xr, d.src_w, cx_lo, w_);
-    }
+    const int x_lo = rows_coord<NEAR>(j_first, d.xr, d.src_w), cx_lo = rows_coord<NEAR>(j_first >> 1, d.xr, d.src_w);
     // plane pointers rounded down to 16 bytes (wave-uniform) + the bytes they were rounded by: every offset below is >= 0
     const uint8_t *fy = t.y[id.frame], *fc = t.uv[id.frame];
     const uint32_t pm_y = (uint32_t)((uintptr_t)fy & 15), pm_c = (uint32_t)((uintptr_t)fc & 15);
@@ -56,20 +68,20 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
 
     uint8_t *wl = lds_raw + wave * d.bc_wave_bytes; // wave-private: segment s at 16 L s
     const int seg_bytes = 16 * L;
-    const int nluma = 2 * nrows;
-    // ---- stage: floor(64 / L) segments per instruction, the luma segments [0, 2 nrows), then the chroma segments [2 nrows, 3 nrows)
+    const int nluma = SPR * nrows, nchroma = SPR * (nrows >> 1);
+    // ---- stage: floor(64 / L) segments per instruction, the luma segments [0, 2 nrows), then the chroma segments [2 nrows, 3 nrows) (POINT: [0, nrows), [nrows, 3 nrows / 2))
     {
         // Lane q evaluates ONCE where luma segment q and chroma segment q start (row offset in bytes): the loops below fetch a segment's offset from the lane that
         // holds it (ds_bpermute) instead of evaluating a coordinate per lane and instruction (the first version: 50 VALU instructions per DMA instruction, ~400 per
         // wave -- with its reads served from cache the launch still took 14 us of its 23: instruction issue, profiles/r05_c3_diag.txt).
         uint32_t ro_y, ro_c;
         {
-            int y, c;
-            float w_;
-            bilinear_axis(min(i_first + (lane >> 1), d.dst_h - 1), d.yr, d.src_h, y, w_);
-            bilinear_axis(min((i_first >> 1) + (lane >> 1), (d.dst_h >> 1) - 1), d.yr, d.src_h, c, w_);
+            const int rq = POINT ? lane : (lane >> 1); // the output row whose segment(s) lane q describes
+            int y = rows_coord<NEAR>(min(i_first + rq, d.dst_h - 1), d.yr, d.src_h);
+            int c = rows_coord<NEAR>(min((i_first >> 1) + rq, (d.dst_h >> 1) - 1), d.yr, d.src_h);
+            y = min(y, d.src_h - 1);
             c = min(c, ch - 1); // (never fires for a valid request, see sample_chroma)
-            if (lane & 1) { // the second row of the pair: y2 = (y + 1 >= rows) ? y : y + 1
+            if (!POINT && (lane & 1)) { // the second row of the pair: y2 = (y + 1 >= rows) ? y : y + 1
                 y = min(y + 1, d.src_h - 1);
                 c = min(c + 1, ch - 1);
             }
@@ -86,11 +98,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
         int ncy, ncc;
         {
             const int j_last = min(j_first + 63, d.dst_w - 1);
-            int xl, cl;
-            float w_;
-            bilinear_axis(j_last, d.xr, d.src_w, xl, w_);
-            bilinear_axis(j_last >> 1, d.xr, d.src_w, cl, w_);
-            const uint32_t by = pm_y + (uint32_t)min(xl + (WX0 ? 0 : 1), d.src_w - 1), bc = pm_c + (uint32_t)min(2 * cl + (WX0 ? 1 : 3), d.src_w - 1);
+            const int xl = rows_coord<NEAR>(j_last, d.xr, d.src_w), cl = rows_coord<NEAR>(j_last >> 1, d.xr, d.src_w);
+            const uint32_t by = pm_y + (uint32_t)min(xl + ((WX0 || POINT) ? 0 : 1), d.src_w - 1), bc = pm_c + (uint32_t)min(2 * cl + ((WX0 || POINT) ? 1 : 3), d.src_w - 1);
             ncy = (int)((by - seg0_y) >> 4) + 1;
             ncc = (int)((bc - seg0_c) >> 4) + 1;
         }
@@ -102,11 +111,11 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_y + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
         if constexpr (!kLumaOnly<OUT>) {
-            for (int s0 = 0; s0 < nrows; s0 += rpi) {
+            for (int s0 = 0; s0 < nchroma; s0 += rpi) {
                 const int q = s0 + lrow;
                 const uint32_t voff = min((uint32_t)__builtin_amdgcn_ds_bpermute(q << 2, (int)ro_c) + cb_c, last_c);
                 uint8_t *dst = wl + (nluma + s0) * seg_bytes;
-                if (lrow < rpi && q < nrows && lchunk < ncc)
+                if (lrow < rpi && q < nchroma && lchunk < ncc)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_c + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             }
         }
@@ -124,7 +133,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
 #pragma unroll
     for (int c = 0; c < PXW; c++) {
         int x;
-        bilinear_axis(jc + c, d.xr, d.src_w, x, wxy[c]);
+        if constexpr (POINT) { x = min(rows_coord<NEAR>(jc + c, d.xr, d.src_w), d.src_w - 1); wxy[c] = 0.0f; }
+        else bilinear_axis(jc + c, d.xr, d.src_w, x, wxy[c]);
         xdy[c] = (x + 1 >= d.src_w) ? 0 : 1;
         py[c] = wl + (pm_y + (uint32_t)x - seg0_y);
     }
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             int x;
-            bilinear_axis((jc >> 1) + c, d.xr, d.src_w, x, wxc[c]);
+            if constexpr (POINT) { x = min(rows_coord<NEAR>((jc >> 1) + c, d.xr, d.src_w), (d.src_w >> 1) - 1); wxc[c] = 0.0f; }
+            else bilinear_axis((jc >> 1) + c, d.xr, d.src_w, x, wxc[c]);
             const int xu = 2 * x, xv = 2 * x + 1;
             du[c] = (xu + 2 >= d.src_w) ? 0 : 2;
             dv[c] = (xv + 2 >= d.src_w) ? 0 : 2;
@@ -145,6 +156,21 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
         const int r0 = sl * 8 + ly * PXH, i0 = i_first + r0;
         if (i0 >= d.dst_h) break;
         float Uf[2] = { 128.0f, 128.0f }, Vf[2] = { 128.0f, 128.0f }, Yf[PXH][PXW];
+        if constexpr (POINT) { // the sample is the byte itself: luma row r0 + r = segment r0 + r, chroma row r0 / 2 = segment nluma + r0 / 2
+#pragma unroll
+            for (int r = 0; r < PXH; r++)
+#pragma unroll
+                for (int c = 0; c < PXW; c++) Yf[r][c] = (float)py[c][(r0 + r) * seg_bytes];
+            if constexpr (!kLumaOnly<OUT>) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    Uf[c] = (float)pc[c][(r0 >> 1) * seg_bytes];
+                    Vf[c] = (float)pc[c][(r0 >> 1) * seg_bytes + 1];
+                }
+            }
+            color_store_tile<OUT, true>(Yf, Uf, Vf, d, (T *)t.out[id.frame], i0, j0, PXW);
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < PXH; r++) {
             int y_;
@@ -201,9 +227,11 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
 
 hipError_t launch_bilinear_rows(OutKind out, const LaunchDesc &d, const FrameTable &t, size_t lds_bytes, hipStream_t stream, LaunchInfo *info) {
     dim3 grid((unsigned)(d.blocks_per_xcd * NUM_XCD)), block((unsigned)(64 * d.br_waves));
-    const bool wx0 = d.wx_zero != 0;
+    const int kind = d.point_kind == PK_NEAREST ? BRK_NEAREST : (d.point_kind != PK_NONE ? BRK_POINT : (d.wx_zero != 0 ? BRK_WX0 : BRK_2X2));
     if (info) {
-        info->kernel = wx0 ? "vpp_bilinear_rows_kernel<OUT, wx0>" : "vpp_bilinear_rows_kernel<OUT, 2x2>";
+        static const char *const names[4] = { "vpp_bilinear_rows_kernel<OUT, 2x2>", "vpp_bilinear_rows_kernel<OUT, wx0>", "vpp_bilinear_rows_kernel<OUT, point>",
+                                              "vpp_bilinear_rows_kernel<OUT, nearest>" };
+        info->kernel = names[kind];
         info->grid = (int)grid.x;
         info->lds_bytes = (int)lds_bytes;
         return hipSuccess;
@@ -211,8 +239,10 @@ hipError_t launch_bilinear_rows(OutKind out, const LaunchDesc &d, const FrameTab
     switch (out) {
 #define TSVPP_BR(O)                                                                                                     \
     case O:                                                                                                             \
-        if (wx0) TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, true>), grid, block, lds_bytes, stream, d, t);          \
-        else TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, false>), grid, block, lds_bytes, stream, d, t);             \
+        if (kind == BRK_NEAREST) TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, BRK_NEAREST>), grid, block, lds_bytes, stream, d, t);  \
+        else if (kind == BRK_POINT) TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, BRK_POINT>), grid, block, lds_bytes, stream, d, t); \
+        else if (kind == BRK_WX0) TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, BRK_WX0>), grid, block, lds_bytes, stream, d, t);     \
+        else TSVPP_LAUNCH((vpp_bilinear_rows_kernel<O, BRK_2X2>), grid, block, lds_bytes, stream, d, t);                          \
         break;
         TSVPP_BR(O_U8_PLANAR) TSVPP_BR(O_U8_MERGED) TSVPP_BR(O_F32_PLANAR) TSVPP_BR(O_F32_MERGED) TSVPP_BR(O_NV12_U8)
         TSVPP_BR(O_NV12_F32) TSVPP_BR(O_Y800_U8) TSVPP_BR(O_Y800_F32) TSVPP_BR(O_HSV_F32)

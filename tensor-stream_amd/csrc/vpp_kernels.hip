@@ -948,6 +948,9 @@ static hipError_t launch_mo(bool vec, bool staged, LaunchDesc &d, const FrameTab
     if constexpr (MODE == M_NEAREST || MODE == M_AREA_UP) {
         if (d.r32 == 20) return launch_point_rn((OutKind)OUT, d, t, stream, info); // pixel replication at 1 : 2 (vpp_point_rn.hip)
     }
+    if constexpr (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC) { // row-segment kernel: sparse BILINEAR, and (round 6) the point samplers at sparse ratios
+        if (d.bil_rows && (MODE == M_BILINEAR || d.point_kind != PK_NONE)) return launch_bilinear_rows((OutKind)OUT, d, t, lds_bytes, stream, info);
+    }
     if (staged && d.point_kind != PK_NONE && (MODE == M_NEAREST || MODE == M_BILINEAR || MODE == M_BICUBIC))
         return launch_point<OUT>(d, t, lds_bytes, stream, info);
     if constexpr (MODE == M_BILINEAR || MODE == M_AREA_DOWN || MODE == M_NEAREST) {

@@ -331,15 +331,23 @@ static void sel_point(Mode mode, bool vec, LaunchDesc &d, FusedSel &S) {
     }
 }
 
-// 6b. BILINEAR at sparse ratios: the tapped rows as LDS-DMA row segments, one wave per 64-column tile (vpp_bilinear_rows.hip)
-static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int stream_r32, LaunchDesc &d, FusedSel &S) {
+// 6b. BILINEAR at sparse ratios -- and, round 6, the pure point samplers at sparse ratios: the tapped rows as LDS-DMA row segments, one wave per 64-column tile
+// (vpp_bilinear_rows.hip).  `point`: the request is a point sampler (NEAREST, or BILINEAR / BICUBIC with all-zero weights; the caller asks BEFORE sel_point).
+static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int stream_r32, bool point, LaunchDesc &d, FusedSel &S) {
     // Until round 4 every BILINEAR request with a ratio product >= 12 ran on the byte-gather kernel (BASELINE config C3: 5.0 x 2.8125).  That kernel is bound by the
     // issue of its gathers -- 64 lanes = 64 cache lines per load instruction -- not by the launch ramp: 64 -> 128 frames took C3 from 23.2 to 50.1 us
     // (profiles/r04_batch128_ab.txt).  Here the tapped rows arrive as contiguous 16-byte chunks.  Needs pitches that are multiples of 16 (every row of a plane then has
     // the same misalignment) and a row segment of at most 64 chunks = ONE DMA instruction (horizontal ratios up to ~15.7).  TSVPP_BILINEAR_ROWS=2 takes every
-    // BILINEAR request that satisfies those two (tests: ratios the LDS-staged kernel serves by default), 0 keeps the gathers.
+    // BILINEAR / point request that satisfies those two (tests: ratios the LDS-staged kernels serve by default), 0 keeps the gathers / the LDS point kernel, 3 = 1 for BILINEAR
+    // only (the point samplers stay on vpp_point_kernel: A/B).
+    if (d.bil_rows) return; // (already chosen for a point request)
     d.bil_rows = 0;
-    if (mode != M_BILINEAR || d.tap22 || S.staged || !vec || d.force_gather || !d.bil_rows_pref || stream_r32) return;
+    if (point) {
+        if (!(mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC) || d.bil_rows_pref == 3) return;
+    } else if (mode != M_BILINEAR || d.tap22 || S.staged) {
+        return;
+    }
+    if (!vec || d.force_gather || !d.bil_rows_pref || stream_r32) return;
     if (!(sparse_gather || d.bil_rows_pref == 2)) return;
     if ((d.pitch_y & 15) != 0 || (d.pitch_uv & 15) != 0) return;
     // bytes a tile's 64 luma columns / 32 chroma pair columns span (+ the right-hand tap, + 1 for the float coordinate), + up to 15 bytes of misalignment, in chunks
@@ -347,7 +355,7 @@ static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int strea
     const int L = ((span_y > span_c ? span_y : span_c) + 30) / 16;
     if (L > 64) return;
     const int rpt = (d.rpt_pref >= 1 && d.rpt_pref <= 4) ? d.rpt_pref : 1; // tile height 8 rows: the most waves in flight (TSVPP_RPT: 16 / 24 / 32)
-    const int wave_bytes = 3 * 8 * rpt * 16 * L + 64;
+    const int wave_bytes = (point ? 12 : 24) * rpt * 16 * L + 64;          // 2 (point: 1) segments per luma row, and per chroma row
     // waves (64-column tiles) per workgroup: the largest of 4 / 2 / 1 that launches no more waves than the narrowest choice (300 columns: five single-wave workgroups
     // instead of two four-wave ones, three of whose waves would exit at once) within 48 KiB of LDS
     int nw = 0;
@@ -500,7 +508,7 @@ static void sel_bicubic_cols(Mode mode, OutKind out, bool vec, int stream_r32, L
     // tile re-evaluates fewer H rows at its seams (3 / (R yr) of them), a shorter one keeps more waves in flight.
     // (not when ANY streaming kernel took the request -- the BICUBIC ones at 3 : 2 / 2 : 1, or a point sampler at an integer ratio: its tables would be built,
     // uploaded and cached for nothing)
-    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && !stream_r32) {
+    if (mode == M_BICUBIC && !staged && vec && !d.force_gather && d.bicubic_cols_pref && !stream_r32 && !d.bil_rows) { // (bil_rows: a zero-weight request on the row-segment kernel)
         const bool sparse = d.yr >= 4.0f;
         const bool exact = d.w_dyadic != 0; // every weight a multiple of 1/16: the quantised coefficients are exact, no tie test
         // LDS-DMA ring: a row segment is (64 columns at ratio xr + window + a misalignment of up to 15 bytes) rounded up to 16-byte chunks,
@@ -581,7 +589,19 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     d.tx = S.shapes[0][0];
     d.ty = S.shapes[0][1];
     sel_area(mode, vec, d, S);
-    sel_point(mode, vec, d, S);
+    // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 and the streaming point samplers (stream_select above); a request that takes one needs neither staging nor tables
+    const int stream_r32 = stream_select(mode, out, vec, d, din.point_kind);
+    // Point samplers at sparse ratios: the row-segment kernel (round 6) instead of vpp_point_kernel's one LDS row per output row behind a workgroup barrier.  Same-box A/B
+    // (profiles/r06_point_rows_ab.txt, NEAREST -> RGB24 planar fp32, launch time at 512 / 256 frames per launch): 1080p -> 224^2 (ratio product 41) 158 -> 112 us,
+    // 4K -> 256^2 137 -> 104, 4K -> 300^2 190 -> 162, 4K -> 416^2 (48) 282 -> 198; even at 1080p -> 256^2 (32) and 4K -> 640^2 (20); 1080p -> 300^2 (23) LOSES 23 %
+    // (206 -> 253 us), 1080p -> 640^2 6 %: the LDS kernel keeps everything below kPointRowsMin.
+    d.bil_rows = 0;
+    {
+        const bool point_req = din.point_kind != PK_NONE && (mode == M_NEAREST || mode == M_BILINEAR || mode == M_BICUBIC);
+        constexpr float kPointRowsMin = 36.0f;
+        if (point_req) sel_bilinear_rows(mode, vec, d.xr * d.yr >= kPointRowsMin, stream_r32, true, d, S);
+    }
+    if (!d.bil_rows) sel_point(mode, vec, d, S);
     d.bicubic_cols = 0;
     d.bc_sparse = 0;
     d.bc_dma = 0;
@@ -591,13 +611,14 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     // 224^2 / 300^2 / 640^2, 4K -> 640x360; C3: 720p crop -> 256^2 = 14, gathers +8 %): BILINEAR gathers win from
     // xr*yr ~ 12 (3.5x at 41), BICUBIC from ~ 30.
     const float ratio_area = d.xr * d.yr;
-    // the streaming kernels at the exact ratios 3 : 2 / 2 : 1 (stream_select above); a BICUBIC request that takes one needs neither staging nor tables
-    const int stream_r32 = stream_select(mode, out, vec, d, din.point_kind);
     const int bc_r32 = (stream_r32 == 7 || stream_r32 == 8) ? stream_r32 : 0;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
     const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
-    const bool sparse_gather = (mode == M_BILINEAR && ratio_area >= 12.0f) || (mode == M_BICUBIC && !bicubic_staged);
-    sel_bilinear_rows(mode, vec, sparse_gather, stream_r32, d, S);
+    // (round 6: BILINEAR leaves the LDS-staged kernel for the row-segment kernel already from a ratio product of 7.5 when the vertical ratio is at least 2.1 -- the staged kernel
+    // fetches every source row of its footprint, the row-segment kernel two per output row: 1080p -> 416^2 (4.6 x 2.6) 561 -> 373 us per 512 frames, -> 480^2 (4 x 2.25) 507 -> 469,
+    // 4K -> 1024^2 (3.75 x 2.1) 285 -> 269; at a vertical ratio of 2.0 and below the staged kernel wins: 1080p -> 540^2 731 vs 756, -> 800^2 912 vs 1079; profiles/r06_point_rows_ab.txt)
+    const bool sparse_gather = (mode == M_BILINEAR && (ratio_area >= 12.0f || (ratio_area >= 7.5f && d.yr >= 2.1f))) || (mode == M_BICUBIC && !bicubic_staged);
+    sel_bilinear_rows(mode, vec, sparse_gather, stream_r32, false, d, S);
     sel_staged(mode, vec, bicubic_staged, sparse_gather, stream_r32, d, S);
     if (d.tap22 && !staged) {
         //  sel_tap22 turned this AREA request into the 2x2-tap kernel's integer tile BEFORE its staging was known to fit; a request that does not fit

@@ -102,3 +102,64 @@ def test_batch_and_frames_far_apart(vpp, oracle):
         ref, _, _ = oracle.convert(ys[f], uvs[f], crop=(0, 0, 1280, 720), dst=(256, 256), resize_type=BILINEAR, fourcc=1, planes=0, normalization=True,
                                    nthreads=8, width=1920)
         assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), f
+
+
+# ---- round 6: the pure point samplers on the same front end (one segment per output row) ------------------------------------------------------------
+NEAR, POINT = "vpp_bilinear_rows_kernel<OUT,nearest>", "vpp_bilinear_rows_kernel<OUT,point>"
+
+
+def run_rt(vpp, oracle, y, uv, w, dst, rt, fourcc=1, planes=0, norm=True, crop=(0, 0, 0, 0), expect=None):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=dst[0], height=dst[1], crop_coords=crop, resize_type=rt, pixel_format=fourcc, planes_pos=planes, normalization=norm)
+    if expect is not None and not KNOBS:
+        k = ts.describe(fp, w, y.shape[0], pitch=y.shape[1])["kernel"]
+        assert k.startswith(expect), k
+    got = vpp.Convert(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda(), fp, width=w)
+    torch.cuda.synchronize()
+    ref, _, _ = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=rt, fourcc=fourcc, planes=planes, normalization=norm, nthreads=8, width=w)
+    g = got.cpu().numpy().ravel()
+    assert g.size == ref.size
+    bad = np.flatnonzero(g.view(np.uint8) != ref.view(np.uint8))
+    assert bad.size == 0, (dst, rt, fourcc, planes, norm, crop, bad[:8], bad.size)
+
+
+@pytest.mark.parametrize("src,dst,rt,kernel", [
+    ((1920, 1080), (224, 224), 0, NEAR),     # NEAREST 8.57 x 4.82
+    ((3840, 2160), (480, 270), 0, NEAR),     # NEAREST 8 x 8 (fp32; uint8 at an exact integer ratio 3 / 4 / 5 only goes to the streaming point sampler)
+    ((3840, 2160), (300, 300), 0, NEAR),     # 12.8 x 7.2: 4 k + ... 300 = 4.7 tiles
+    ((3840, 2160), (256, 144), 1, POINT),    # BILINEAR 15 x 15: every weight zero
+    ((3840, 2160), (256, 144), 2, POINT),    # BICUBIC  15 x 15: every weight zero -> the centre tap
+    ((1920, 1080), (128, 72), 1, POINT),     # BILINEAR 15 x 15 from 1080p
+    ((1920, 1080), (174, 98), 0, NEAR),      # 11.03 x 11.02: 4 k + 2 columns, partial bottom tile
+])
+def test_point_samplers_on_row_segments(vpp, oracle, src, dst, rt, kernel):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0] + rt, pitch=(src[0] + 15) // 16 * 16)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, planes=0, norm=True, expect=kernel)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, planes=1, norm=False)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, fourcc=3, planes=1, norm=False)   # NV12
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, fourcc=0, planes=1, norm=True)    # Y800: the chroma plane is neither staged nor sampled
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, fourcc=6, planes=1, norm=True)    # HSV
+
+
+def test_point_samplers_crops_edges_and_pitches(vpp, oracle):
+    y, uv = synth_nv12(3840, 2160, seed=4242, pitch=3840)
+    run_rt(vpp, oracle, y, uv, 3840, (310, 178), 0, crop=(121, 65, 3321, 1865), expect=NEAR)            # odd origin: U / V swap quirk, unaligned planes; width 4 k + 2
+    run_rt(vpp, oracle, y, uv, 3840, (310, 178), 0, crop=(121, 65, 3321, 1865), planes=1, norm=False)
+    run_rt(vpp, oracle, y, uv, 3840, (250, 100), 0, crop=(1840, 1160, 3840, 2160), expect=NEAR)         # the bottom-right corner: the planes' last rows and bytes
+    run_rt(vpp, oracle, y, uv, 3840, (62, 30), 0, crop=(12, 4, 2012, 964))                              # narrower than a tile, 4 k + 2
+    y2, uv2 = synth_nv12(1920, 1080, seed=4343, pitch=1925)                                             # pitch % 16 != 0: not this kernel (same bits)
+    run_rt(vpp, oracle, y2, uv2, 1920, (224, 224), 0, expect="vpp_point_kernel" if not KNOBS else None)
+
+
+def test_point_rows_batch(vpp, oracle):
+    import tensor_stream as ts
+    fp = ts.FrameParameters(width=224, height=224, resize_type=0, pixel_format=2, planes_pos=0, normalization=True)
+    n = 40
+    rng = np.random.default_rng(6)
+    ys = rng.integers(0, 256, (n, 1080, 1920), dtype=np.uint8)
+    uvs = rng.integers(0, 256, (n, 540, 1920), dtype=np.uint8)
+    out = vpp.convert_batch(torch.from_numpy(ys).cuda(), torch.from_numpy(uvs).cuda(), fp)
+    torch.cuda.synchronize()
+    for f in (0, 17, 39):
+        ref, _, _ = oracle.convert(ys[f], uvs[f], dst=(224, 224), resize_type=0, fourcc=2, planes=0, normalization=True, nthreads=8)
+        assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), f

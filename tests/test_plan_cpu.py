@@ -67,7 +67,10 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((3840, 2160), (1280, 720), C, "vpp_point_kernel<PK_BICUBIC0"),         # C4's geometry, fp32 output: every cubic weight is zero -> LDS point kernel
     ((3840, 2160), (1280, 720), B, "vpp_point_kernel<PK_BILINEAR0"),
     ((1960, 1120), (280, 160), B, "vpp_point_kernel<PK_BILINEAR0"),         # 7 : 1: all weights zero, no streaming instance -> LDS point kernel
-    ((3840, 2160), (480, 270), N, "vpp_point_kernel<PK_NEAREST"),           # 8 : 1
+    ((3840, 2160), (480, 270), N, "vpp_bilinear_rows_kernel<OUT,nearest>"),  # 8 : 1 -- ratio product >= 36: the tapped rows as LDS-DMA row segments (round 6; vpp_point_kernel before)
+    ((1920, 1080), (300, 300), N, "vpp_point_kernel<PK_NEAREST"),            # 6.4 x 3.6 = 23: the LDS point kernel keeps it (measured 23 % faster there)
+    ((1920, 1080), (384, 216), B, "vpp_point_kernel<PK_BILINEAR0"),          # 5 x 5, all weights zero: a point sampler, below the threshold
+    ((3840, 2160), (256, 144), C, "vpp_bilinear_rows_kernel<OUT,point>"),    # 15 x 15, all weights zero
     ((1920, 1080), (1280, 720), N, "vpp_point_kernel<PK_NEAREST"),
     ((3840, 2160), (640, 360), A, "vpp_area_box_kernel<6,1"),            # C5: 6 x 6 box from contiguous dword runs
     ((3840, 2160), (960, 540), A, "vpp_area_box_kernel<4,1"),            # 4 x 4
@@ -100,6 +103,8 @@ def test_headline_runs_the_dma_staged_bilinear_kernel_on_256x8_tiles():
     ((1920, 1080), (224, 224), C, "vpp_bicubic_cols_kernel<OUT,tie,sparse>"),    # vertical ratio >= 4: only the tapped rows are evaluated
     ((3840, 2160), (640, 360), C, "vpp_bicubic_cols_kernel<OUT,exact,sparse>"),  # 6: dyadic, but too sparse for the staged integer kernel
     ((1920, 1080), (224, 224), B, "vpp_bilinear_rows_kernel<OUT,2x2>"),  # very sparse sampling: the tapped rows as LDS-DMA row segments (round 5; byte gathers before)
+    ((1920, 1080), (416, 416), B, "vpp_bilinear_rows_kernel<OUT,2x2>"),  # 4.6 x 2.6 = 11.98: from a product of 7.5 on when the vertical ratio is >= 2.1 (round 6: 561 -> 373 us per 512 frames)
+    ((1920, 1080), (540, 540), B, "vpp_bilinear_kernel<bilinear"),       # 3.56 x 2.0: the LDS-staged kernel keeps vertical ratios up to 2
 ])
 def test_kernel_families(src, dst, rt, kernel):
     p = plan(src, dst, rt)
