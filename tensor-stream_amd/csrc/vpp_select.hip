@@ -145,7 +145,7 @@ static void sel_tap22(Mode &mode, OutKind out, bool vec, LaunchDesc &d) {
     // TSVPP_BILINEAR_INT=0 / 2 switch it off.
     d.tap22 = 0;
     {
-        const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32);
+        const bool f32 = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32); // (Y800: round 6, with two row pairs per thread -- see sel_staged)
         const bool r32x = 2L * d.src_w == 3L * d.dst_w && 2L * d.src_h == 3L * d.dst_h, r21 = d.src_w == 2 * d.dst_w && d.src_h == 2 * d.dst_h;
         // (4 k + 2 columns: the tail launch samples by MODE)
         if (!d.tap22_off && f32 && vec && !d.force_gather && d.bil_int_pref == 1 && d.r32_pref != 2 && (r32x || r21) && (d.dst_w & 3) == 0 && mode == M_AREA_DOWN && d.qx && d.qy &&
@@ -401,7 +401,9 @@ static void sel_staged(Mode mode, bool vec, bool bicubic_staged, bool sparse_gat
             // table build over more pixels -- that pays where the kernel is VALU-bound (uint8 outputs, separable BICUBIC, the
             // AREA kernels: two row pairs) -- but the fp32 2x2-tap kernel is bound by the HBM write pattern, which prefers
             // SHORT tiles (round 2 sweep: one row pair wins by 2..9 % on 1080p -> 720p, 4K -> 1080p and 720p -> 1080p).
-            const int rpt_auto = (two_tap && f32_out) ? 1 : 2;
+            // ... except its luma-only flavour (Y800 fp32, round 6): a third of the output bytes per tile for the same staging set-up -- two row pairs per thread 0.565 -> 0.740 of the
+            // roofline (1080p -> 720p, profiles/r06_fmt_ab.txt; NV12 fp32 is indifferent: 0.731 / 0.734)
+            const int rpt_auto = (two_tap && f32_out && !d.luma_only) ? 1 : 2;
             const int rpt_want = d.rpt_pref >= 1 && d.rpt_pref <= 8 ? d.rpt_pref : rpt_auto;
             int rpt_max = (two_tap || bint || area2 || dyadic) ? rpt_want : 1;
             // taller thread tiles only while the launch still has at least two full rounds of workgroups

@@ -39,7 +39,8 @@ def run(vpp, oracle, y, uv, w, dst, rt, fourcc=2, planes=1, norm=False, crop=(0,
     ((1920, 1080), (384, 216), BILINEAR, "vpp_point_rn_kernel<OUT,5:1,centre>"),
     ((1920, 1080), (384, 216), BICUBIC, "vpp_point_rn_kernel<OUT,5:1,centre>"),
     ((1920, 1080), (384, 216), NEAREST, "vpp_point_rn_kernel<OUT,5:1,nearest>"),
-    ((1920, 1080), (320, 180), NEAREST, "vpp_point_kernel"),                        # 6 : 1: the LDS point kernel
+    ((1920, 1080), (320, 180), NEAREST, "vpp_bilinear_rows_kernel<OUT,nearest>"),   # 6 : 1 -- no streaming instance: ratio product 36, the row-segment kernel (round 6; the LDS point kernel before)
+    ((1920, 1080), (480, 216), NEAREST, "vpp_point_kernel"),                        # 4 x 5 = 20: the LDS point kernel
     ((1920, 1080), (1280, 360), BILINEAR, None),                                    # 1.5 x 3: not a point sampler
 ])
 def test_instances(vpp, oracle, src, dst, rt, kernel):
