@@ -31,7 +31,7 @@ def check(vpp, oracle, y, uv, w, dst, rt, fourcc=2, planes=0, norm=True, crop=(0
         assert bad.size == 0, (w, y.shape, dst, rt, fourcc, planes, crop, n, bad[:8], bad.size)
 
 
-@pytest.mark.parametrize("fourcc,planes", [(2, 0), (1, 1), (3, 1)])  # fp32 planar / merged, NV12
+@pytest.mark.parametrize("fourcc,planes", [(2, 0), (1, 1), (3, 1), (0, 1)])  # fp32 planar / merged, NV12, Y800 (round 6)
 @pytest.mark.parametrize("src,pitch,dst,rt", [((960, 540), 960, (640, 360), AREA), ((960, 540), 1001, (640, 360), AREA),                                               ((1280, 720), 1280, (640, 360), AREA), ((1288, 724), 1290, (644, 362), AREA),
                                               ((48, 24), 48, (32, 16), AREA), ((16, 8), 16, (8, 4), AREA)])
 def test_flavours_pitches_sizes(vpp, oracle, src, pitch, dst, rt, fourcc, planes):
@@ -47,7 +47,7 @@ def test_full_sizes_batches_crops_and_what_it_leaves_alone(vpp, oracle):
     check(vpp, oracle, y, uv, 1920, (640, 360), AREA, crop=(13, 7, 973, 547))                  # odd origin (U / V swap quirk), 3 : 2
     check(vpp, oracle, y, uv, 1920, (640, 360), AREA, crop=(64, 32, 1024, 572), planes=1)
     check(vpp, oracle, y, uv, 1920, (480, 270), AREA, crop=(2, 2, 962, 542))                   # 2 : 1, 270 rows
-    check(vpp, oracle, y, uv, 1920, (1280, 720), AREA, fourcc=0, planes=1, expect=False)       # Y800: measured slower there
+    check(vpp, oracle, y, uv, 1920, (1280, 720), AREA, fourcc=0, planes=1, expect=True)        # Y800 fp32 (round 6, two row pairs per thread: 0.62 -> 0.74; slower before that)
     check(vpp, oracle, y, uv, 1920, (1280, 720), AREA, norm=False, expect=False)               # uint8: the streaming kernel
     check(vpp, oracle, y, uv, 1920, (1280, 720), AREA, fourcc=6, planes=1, expect=False)       # HSV: the streaming kernel
     check(vpp, oracle, y, uv, 1920, (1280, 540), AREA, expect=False)                           # 1.5 x 2: not one of the two ratios
