@@ -1195,6 +1195,10 @@ def run(args):
                          "avg_launch_ms": round(kernel_ms, 5), "host_issue_ms_per_step": round(host_issue * 1e3 / args.steps, 4)},
         }
         if args.consumers:
+            # the rank's consumers convert the SAME published frame (that IS C5's shape: consumers of one stream): its source bytes leave HBM once per step, the rest are cache hits --
+            # `frac` (ROI formula per conversion) says how well the entry keeps the GPU fed, `shared_source_frac` prices the bytes that really move (one source frame + every output)
+            src_b = bytes_per_frame - write_bytes_per_frame
+            res["roofline"]["shared_source_frac"] = round((src_b + eng.n * write_bytes_per_frame) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             res["config"]["consumers"] = {"total": args.consumers, "per_rank": eng.n, "entry": "TensorStreamConverter.read_many (one batched launch per published frame)",
                                           "names_rank0": [eng.names[0], eng.names[-1]], "sharding": "consumer c -> rank c // (consumers / world): each rank its own converter, source and stream pool"}
         if per_rank:
