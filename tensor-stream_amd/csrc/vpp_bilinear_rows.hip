@@ -89,7 +89,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
             ro_c = (uint32_t)c * (uint32_t)d.pitch_uv;
         }
         const int lrow = (lane * (65536 / L + 1)) >> 16, lchunk = lane - lrow * L; // lane / L, lane % L (lane < 64 <= 65536 / L: exact)
-        const int rpi = d.br_rpi;                                                  // 64 / L
+        const int rpi = d.br_rpi;                                                  // 64 / L; 0: a segment is wider than one instruction (L > 64)
         const uint32_t last_y = ((uint32_t)(d.src_h - 1) * (uint32_t)d.pitch_y + pm_y + (uint32_t)d.src_w - 1u) & ~15u;  // the planes' last valid chunks
         const uint32_t last_c = ((uint32_t)(ch - 1) * (uint32_t)d.pitch_uv + pm_c + (uint32_t)d.src_w - 1u) & ~15u;
         const uint32_t cb_y = seg0_y + 16u * (uint32_t)lchunk, cb_c = seg0_c + 16u * (uint32_t)lchunk;
@@ -103,20 +103,47 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_rows_kernel(const La
             ncy = (int)((by - seg0_y) >> 4) + 1;
             ncc = (int)((bc - seg0_c) >> 4) + 1;
         }
-        for (int s0 = 0; s0 < nluma; s0 += rpi) {
-            const int q = s0 + lrow;
-            const uint32_t voff = min((uint32_t)__builtin_amdgcn_ds_bpermute(q << 2, (int)ro_y) + cb_y, last_y); // chunks past a plane's end hold bytes no tap reads
-            uint8_t *dst = wl + s0 * seg_bytes; // wave-uniform
-            if (lrow < rpi && q < nluma && lchunk < ncy)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_y + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
-        if constexpr (!kLumaOnly<OUT>) {
-            for (int s0 = 0; s0 < nchroma; s0 += rpi) {
+        if (rpi > 0) {
+            for (int s0 = 0; s0 < nluma; s0 += rpi) {
                 const int q = s0 + lrow;
-                const uint32_t voff = min((uint32_t)__builtin_amdgcn_ds_bpermute(q << 2, (int)ro_c) + cb_c, last_c);
-                uint8_t *dst = wl + (nluma + s0) * seg_bytes;
-                if (lrow < rpi && q < nchroma && lchunk < ncc)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_c + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                const uint32_t voff = min((uint32_t)__builtin_amdgcn_ds_bpermute(q << 2, (int)ro_y) + cb_y, last_y); // chunks past a plane's end hold bytes no tap reads
+                uint8_t *dst = wl + s0 * seg_bytes; // wave-uniform
+                if (lrow < rpi && q < nluma && lchunk < ncy)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_y + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
+            if constexpr (!kLumaOnly<OUT>) {
+                for (int s0 = 0; s0 < nchroma; s0 += rpi) {
+                    const int q = s0 + lrow;
+                    const uint32_t voff = min((uint32_t)__builtin_amdgcn_ds_bpermute(q << 2, (int)ro_c) + cb_c, last_c);
+                    uint8_t *dst = wl + (nluma + s0) * seg_bytes;
+                    if (lrow < rpi && q < nchroma && lchunk < ncc)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_c + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                }
+            }
+        } else {
+            // (round 6) a segment of 65 .. 128 chunks -- horizontal ratios 15.7 .. 31: 4K -> 224 x 224 is 17.1 -- takes TWO instructions: lane l fetches chunk l, then chunk 64 + l; the
+            // segment's row offset is wave-uniform (v_readlane of the lane that evaluated it).  These requests ran on the byte-gather kernel until round 6.
+            for (int sg = 0; sg < nluma; sg++) {
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)ro_y, sg);
+                for (int k = 0; 64 * k < L; k++) {
+                    const int chunk = lane + 64 * k;
+                    const uint32_t voff = min(row + seg0_y + 16u * (uint32_t)chunk, last_y);
+                    uint8_t *dst = wl + sg * seg_bytes + 1024 * k;
+                    if (chunk < ncy)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_y + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                }
+            }
+            if constexpr (!kLumaOnly<OUT>) {
+                for (int sg = 0; sg < nchroma; sg++) {
+                    const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)ro_c, sg);
+                    for (int k = 0; 64 * k < L; k++) {
+                        const int chunk = lane + 64 * k;
+                        const uint32_t voff = min(row + seg0_c + 16u * (uint32_t)chunk, last_c);
+                        uint8_t *dst = wl + (nluma + sg) * seg_bytes + 1024 * k;
+                        if (chunk < ncc)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(plane_c + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    }
+                }
             }
         }
     }

@@ -353,7 +353,9 @@ static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int strea
     // bytes a tile's 64 luma columns / 32 chroma pair columns span (+ the right-hand tap, + 1 for the float coordinate), + up to 15 bytes of misalignment, in chunks
     const int span_y = (int)(63.0 * (double)d.xr) + 3, span_c = 2 * ((int)(31.0 * (double)d.xr) + 3);
     const int L = ((span_y > span_c ? span_y : span_c) + 30) / 16;
-    if (L > 64) return;
+    // (round 6: up to 128 chunks -- two instructions per segment, horizontal ratios up to ~31: 4K -> 224 x 224 -- instead of the byte-gather kernel; TSVPP_BILINEAR_ROWS_WAVES=9 keeps the
+    // one-instruction limit for an A/B)
+    if (L > 128 || (L > 64 && d.br_waves == 9)) return;
     const int rpt = (d.rpt_pref >= 1 && d.rpt_pref <= 4) ? d.rpt_pref : 1; // tile height 8 rows: the most waves in flight (TSVPP_RPT: 16 / 24 / 32)
     const int wave_bytes = (point ? 12 : 24) * rpt * 16 * L + 64;          // 2 (point: 1) segments per luma row, and per chroma row
     // waves (64-column tiles) per workgroup: the largest of 4 / 2 / 1 that launches no more waves than the narrowest choice (300 columns: five single-wave workgroups
@@ -362,7 +364,7 @@ static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int strea
     long best = 0;
     for (int w = 4; w >= 1; w >>= 1) {
         if ((long)w * wave_bytes > 48 * 1024) continue;
-        if (d.br_waves && d.br_waves != w) continue; // TSVPP_BILINEAR_ROWS_WAVES (A/B)
+        if (d.br_waves && d.br_waves != 9 && d.br_waves != w) continue; // TSVPP_BILINEAR_ROWS_WAVES (A/B)
         const long waves = (long)((d.dst_w + 64 * w - 1) / (64 * w)) * w;
         if (!nw || waves < best) {
             nw = w;
@@ -371,7 +373,7 @@ static void sel_bilinear_rows(Mode mode, bool vec, bool sparse_gather, int strea
     }
     if (!nw) return;
     d.bil_rows = L;
-    d.br_rpi = 64 / L;
+    d.br_rpi = 64 / L; // (0: two instructions per segment)
     d.br_waves = nw;
     d.bc_wave_bytes = wave_bytes;
     S.br_lds = (size_t)nw * wave_bytes;

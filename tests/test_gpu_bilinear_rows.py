@@ -163,3 +163,18 @@ def test_point_rows_batch(vpp, oracle):
     for f in (0, 17, 39):
         ref, _, _ = oracle.convert(ys[f], uvs[f], dst=(224, 224), resize_type=0, fourcc=2, planes=0, normalization=True, nthreads=8)
         assert np.array_equal(out[f].cpu().numpy().ravel().view(np.uint8), ref.view(np.uint8)), f
+
+
+@pytest.mark.parametrize("src,dst,rt,kernel", [
+    ((3840, 2160), (224, 224), 0, NEAR),     # NEAREST 17.1 x 9.6: 70 chunks per segment -- two DMA instructions per segment (round 6; byte gathers before)
+    ((3840, 2160), (224, 224), 1, TWO),      # BILINEAR, the same geometry
+    ((3840, 2160), (128, 72), 1, TWO),       # 30 x 30 (weights 0.5): 120 chunks, the widest segment
+    ((3840, 2160), (160, 90), 0, NEAR),      # 24 x 24
+    ((3840, 1080), (150, 300), 1, TWO),      # 25.6 x 3.6: 4 k + 2 columns, partial tiles
+])
+def test_segments_wider_than_one_instruction(vpp, oracle, src, dst, rt, kernel):
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + dst[0] + 7 * rt, pitch=(src[0] + 15) // 16 * 16)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, planes=0, norm=True, expect=kernel)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, planes=1, norm=False)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, fourcc=3, planes=1, norm=False)
+    run_rt(vpp, oracle, y, uv, src[0], dst, rt, crop=(101, 51, 3701, 2051) if src[1] == 2160 else (101, 51, 3701, 1051))  # odd origin: misaligned planes, U / V swap quirk
