@@ -20,6 +20,10 @@ WORLD_SIZE in the environment) or by this script itself when `--gpus N` is given
 scaling); the only collective is a one-off RCCL broadcast of the 8 colour coefficients, verified against the
 compiled-in defaults.  With fewer than N GPUs visible it prints a "not measured" line instead of extrapolating.
 
+Besides the timed region the default line carries (world 1): the headline's other resize types and every BASELINE configuration (`config.other_workloads`), the facade leg, the
+single-frame latency leg and -- round 6 -- `config.launch_curve`: the headline, C3 and C4 at 1 .. 64 frames per launch (tensor-stream_amd/cpp/vpp_curve.cpp, its own process), the reference's
+real calling pattern.  `--workload c5 --consumers 64` makes the step ONE read_many over this rank's share of 64 named consumers of a TensorStreamConverter (C5 as BASELINE words it).
+
 The oracle (oracle/) is touched only as the checker: the parity gate (AFTER the timed region, on frames 0 / 31 / 63 of the
 buffer set the last timed step wrote -- the timed launch is the checked launch), `touched_bytes`,
 and the `cpu_baseline` leg.  A failure in a side leg (cpu_baseline, other_resize_types, traffic lookup) is
