@@ -127,6 +127,24 @@ __device__ __forceinline__ int bc_isum(uint32_t taps, int l0, int l1, int l2, in
     const uint32_t s1 = __builtin_amdgcn_udot4(x, (uint32_t)l1, s2 << 8, false);
     return (int)__builtin_amdgcn_udot4(x, (uint32_t)l0, (s1 << 8) + (uint32_t)bias, false);
 }
+// Four sums at once, STAGE by stage (round 6).  gfx950 needs wait states between a v_dot4 and the instruction that consumes its result; with the four chains of a group
+// written one after the other (bc_isum x 4) the compiler kept them sequential and filled every gap with `s_nop 2` -- 49 scalar-slot instructions per 4 sums in the ISA of round 5,
+// a dependent chain of ~40 cycles per sum.  Written stage-wise the four independent chains fill each other's wait states.
+__device__ __forceinline__ void bc_isum4(const uint32_t (&tp)[4], const int (&l0)[4], const int (&l1)[4], const int (&l2)[4], const int (&bias)[4], int (&s)[4]) {
+    uint32_t x[4], a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = tp[k] ^ 0xff0000ffu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = __builtin_amdgcn_udot4(x[k], (uint32_t)l2[k], 0u, false);
+#pragma unroll
+    for (int k = 0; k < 4; k++) b[k] = __builtin_amdgcn_udot4(x[k], (uint32_t)l1[k], a[k] << 8, false);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = (int)__builtin_amdgcn_udot4(x[k], (uint32_t)l0[k], (b[k] << 8) + (uint32_t)bias[k], false);
+}
+__device__ __forceinline__ void bc_isum4(const uint32_t (&tp)[4], int l0, int l1, int l2, int bias, int (&s)[4]) {
+    const int a0[4] = { l0, l0, l0, l0 }, a1[4] = { l1, l1, l1, l1 }, a2[4] = { l2, l2, l2, l2 }, ab[4] = { bias, bias, bias, bias };
+    bc_isum4(tp, a0, a1, a2, ab, s);
+}
 // distance-to-tie key: small (< 2 BC_TIE << 10) iff the sum is within BC_TIE units of a rounding tie
 __device__ __forceinline__ uint32_t bc_tie_key(int s) { return (uint32_t)(s + BC_TIE) << (32 - BC_SHIFT); }
 constexpr uint32_t BC_TIE_KEY = (2u * BC_TIE) << (32 - BC_SHIFT);
@@ -275,8 +293,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
                 slot = slot == 2 ? 0 : slot + 1;
             }
             int s[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
+            bc_isum4(tp, ax.l0, ax.l1, ax.l2, ax.bias, s);
             *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w, exm);
         }
     } else {
@@ -325,8 +342,7 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
 #pragma unroll
             for (int k = 0; k < 4; k++) tp[k] = bc_taps<STEP, NDW>(dw[k], sh[k], aligned ? selx_c : (STEP == 1 ? tapsel + rep4(sh[k]) : tapsel));
             int s[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) s[k] = bc_isum(tp[k], ax.l0, ax.l1, ax.l2, ax.bias);
+            bc_isum4(tp, ax.l0, ax.l1, ax.l2, ax.bias, s);
             *(uint32_t *)(hcol + 4 * g) = bc_finish4<EXACT>(s, tp, ax.w, ax.w, ax.w, ax.w, exm);
         };
         // leading groups whose rows all lie above the plane's last row
@@ -379,7 +395,11 @@ __device__ __forceinline__ void bc_plane(const uint8_t *frame_plane, int pitch, 
             const uint32_t *p = (const uint32_t *)(hcol + (off & ~3));
             const uint32_t win = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off & 3u);
             tp[e] = SPARSE ? win : __builtin_amdgcn_perm(0u, win, (uint32_t)sel4[e]);
-            s[e] = bc_isum(tp[e], a4[e], b4[e], c4[e], bias4[e]);
+        }
+        {
+            const int q0[4] = { a4[0], a4[1], a4[2], a4[3] }, q1[4] = { b4[0], b4[1], b4[2], b4[3] }, q2[4] = { c4[0], c4[1], c4[2], c4[3] },
+                      qb[4] = { bias4[0], bias4[1], bias4[2], bias4[3] };
+            bc_isum4(tp, q0, q1, q2, qb, s);
         }
         uint32_t r = bc_pack4(s[0], s[1], s[2], s[3]);
         if constexpr (!EXACT) {

@@ -669,16 +669,22 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
             const int r0 = (TH / 4) * wave + 2 * rp;
             const int iA = min(i_first + r0, d.dst_h - 1), iB = min(i_first + r0 + 1, d.dst_h - 1);
             const float *wyA = d.paty4 + (iA % d.ny) * 4 * d.nky, *wyB = d.paty4 + (iB % d.ny) * 4 * d.nky;
-            const int yA = (int)(d.yr * (float)iA), yB = (int)(d.yr * (float)iB);
+            // (wave-uniform, but evaluated on the vector unit -- gfx950 has no scalar float unit: back into SGPRs, so that the loads' edge test is a scalar branch)
+            const int yA = __builtin_amdgcn_readfirstlane((int)(d.yr * (float)iA)), yB = __builtin_amdgcn_readfirstlane((int)(d.yr * (float)iB));
             f2 acc = { 0.0f, 0.0f }, div = { 0.0f, 0.0f };
-            for (int a = 0; a < d.ry; a++) {
+            // (round 6) the rows of tap row a + 1 are requested BEFORE tap row a is accumulated: the kernel waits (61 % of its wave cycles in SQ_WAIT_ANY at 1080p -> 300 x 300,
+            // VALU a third of the launch: profiles/HISTORY.md) -- two row pairs in flight per wave instead of one: 1080p -> 300 x 300 543 -> 491 us per 512 frames
+            // (profiles/r06_area_cols_ab.txt).  Measured and NOT taken: the divisor from the host-built table (LaunchDesc::area_div) instead of the running sum -- its two
+            // scattered loads and integer modulos per lane cost more than the packed add they save (300^2: 524 us, 416^2: 713 against 643).
+            // tap rows [0, a_wide) lie above the plane's last row for BOTH output rows: unconditional 12- / 8-byte loads, no branch between them (the edge test
+            // inside the loop made the compiler wait for every load before it issued the next: `s_waitcnt vmcnt(0)` in front of each in round 5's ISA); the plane's
+            // last row -- bottom tiles only -- keeps the dword-by-dword loads that never read past it
+            const int a_wide = min(max(d.src_h - 1 - yB, 0), d.ry);
+            auto accum = [&](int a, const uint32_t (&qa)[NK + 1], const uint32_t (&qb)[NK + 1], uint32_t qsa, uint32_t qsb) {
                 const f2 wy = { wyA[a], wyB[a] };
-                uint32_t da[NK + 1], db[NK + 1], sa, sb;
-                cols_load<NK>(Y, ym, (uint32_t)(yA + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yA + a) < d.src_h - 1, da, sa);
-                cols_load<NK>(Y, ym, (uint32_t)(yB + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yB + a) < d.src_h - 1, db, sb);
 #pragma unroll
                 for (int k = 0; k < NK; k++) {
-                    const uint32_t va = __builtin_amdgcn_alignbyte(da[k + 1], da[k], sa), vb = __builtin_amdgcn_alignbyte(db[k + 1], db[k], sb);
+                    const uint32_t va = __builtin_amdgcn_alignbyte(qa[k + 1], qa[k], qsa), vb = __builtin_amdgcn_alignbyte(qb[k + 1], qb[k], qsb);
                     const float wk[4] = { wx[k].x, wx[k].y, wx[k].z, wx[k].w };
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
@@ -687,6 +693,37 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
                         acc = __builtin_elementwise_fma((f2){ (float)((va >> (8 * b)) & 255), (float)((vb >> (8 * b)) & 255) }, wgt, acc);
                     }
                 }
+            };
+            auto load_wide = [&](int a, uint32_t (&qa)[NK + 1], uint32_t (&qb)[NK + 1], uint32_t &qsa, uint32_t &qsb) {
+                if constexpr (NK <= 2) {
+                    load_span<NK, true>(Y, ym, (uint32_t)(yA + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, qa, qsa);
+                    load_span<NK, true>(Y, ym, (uint32_t)(yB + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, qb, qsb);
+                } else {
+                    cols_load<NK>(Y, ym, (uint32_t)(yA + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, true, qa, qsa);
+                    cols_load<NK>(Y, ym, (uint32_t)(yB + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, true, qb, qsb);
+                }
+            };
+            int a = 0;
+            if (a_wide > 0) {
+                uint32_t da[NK + 1], db[NK + 1], sa, sb;
+                load_wide(0, da, db, sa, sb);
+                for (; a + 1 < a_wide; a++) { // tap row a + 1 is in flight while tap row a is accumulated
+                    uint32_t na[NK + 1], nb[NK + 1], nsa, nsb;
+                    load_wide(a + 1, na, nb, nsa, nsb);
+                    accum(a, da, db, sa, sb);
+#pragma unroll
+                    for (int k = 0; k <= NK; k++) { da[k] = na[k]; db[k] = nb[k]; }
+                    sa = nsa;
+                    sb = nsb;
+                }
+                accum(a, da, db, sa, sb);
+                a++;
+            }
+            for (; a < d.ry; a++) { // the plane's last row
+                uint32_t da[NK + 1], db[NK + 1], sa, sb;
+                cols_load<NK>(Y, ym, (uint32_t)(yA + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yA + a) < d.src_h - 1, da, sa);
+                cols_load<NK>(Y, ym, (uint32_t)(yB + a) * (uint32_t)d.pitch_y + (uint32_t)x0, d.rx, (yB + a) < d.src_h - 1, db, sb);
+                accum(a, da, db, sa, sb);
             }
             yt[r0][lane] = __builtin_truncf(acc.x / div.x);
             yt[r0 + 1][lane] = __builtin_truncf(acc.y / div.y);
@@ -707,24 +744,15 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
             const int y0 = (int)(d.yr * (float)ci);
             f2 acc = { 0.0f, 0.0f };
             float div = 0.0f;
-            for (int a = 0; a < d.ry; a++) {
+            const int ch_rows = d.src_h >> 1;
+            // (as the luma loop: the rows above the plane's last one -- for the LOWER of the wave's two chroma rows, lanes 32-63 -- with unconditional loads, one tap row ahead)
+            const int a_wide = min(max(ch_rows - 1 - __builtin_amdgcn_readlane(y0, 63), 0), d.ry);
+            auto accum = [&](int a, const uint32_t (&q)[2 * NK + 1], uint32_t qsh) {
                 const float wy = wyrow[a];
-                const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_uv + (uint32_t)x0;
-                const bool wide = (y0 + a) < (d.src_h >> 1) - 1;
-                uint32_t dw[2 * NK + 1], sh;
-                if constexpr (NK == 1) {
-                    if (wide) load_span<2, true>(UV, uvm, row, 2 * d.rx, dw, sh);
-                    else load_span<2, false>(UV, uvm, row, 2 * d.rx, dw, sh);
-                } else {
-                    sh = (uvm + row) & 3u;
-                    const uint32_t *p = (const uint32_t *)(UV + (row + uvm - sh));
-#pragma unroll
-                    for (int k = 0; k <= 2 * NK; k++) dw[k] = p[(wide || 4 * k < (int)sh + 2 * d.rx) ? k : 0];
-                }
 #pragma unroll
                 for (int k = 0; k < NK; k++) {
-                    const uint32_t v0 = __builtin_amdgcn_alignbyte(dw[2 * k + 1], dw[2 * k], sh);     // U0 V0 U1 V1
-                    const uint32_t v1 = __builtin_amdgcn_alignbyte(dw[2 * k + 2], dw[2 * k + 1], sh); // U2 V2 U3 V3
+                    const uint32_t v0 = __builtin_amdgcn_alignbyte(q[2 * k + 1], q[2 * k], qsh);     // U0 V0 U1 V1
+                    const uint32_t v1 = __builtin_amdgcn_alignbyte(q[2 * k + 2], q[2 * k + 1], qsh); // U2 V2 U3 V3
                     const float wv[4] = { wx[k].x, wx[k].y, wx[k].z, wx[k].w };
                     const uint32_t vv[2] = { v0, v1 };
 #pragma unroll
@@ -735,6 +763,38 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_area_cols_kernel(const Launch
                         acc = __builtin_elementwise_fma((f2){ (float)(qq & 255), (float)((qq >> 8) & 255) }, (f2){ wgt, wgt }, acc);
                     }
                 }
+            };
+            auto load_row = [&](int a, bool wide, uint32_t (&q)[2 * NK + 1], uint32_t &qsh) {
+                const uint32_t row = (uint32_t)(y0 + a) * (uint32_t)d.pitch_uv + (uint32_t)x0;
+                if constexpr (NK == 1) {
+                    if (wide) load_span<2, true>(UV, uvm, row, 2 * d.rx, q, qsh);
+                    else load_span<2, false>(UV, uvm, row, 2 * d.rx, q, qsh);
+                } else {
+                    qsh = (uvm + row) & 3u;
+                    const uint32_t *p = (const uint32_t *)(UV + (row + uvm - qsh));
+#pragma unroll
+                    for (int k = 0; k <= 2 * NK; k++) q[k] = p[(wide || 4 * k < (int)qsh + 2 * d.rx) ? k : 0];
+                }
+            };
+            int a = 0;
+            if (a_wide > 0) {
+                uint32_t dw[2 * NK + 1], sh;
+                load_row(0, true, dw, sh);
+                for (; a + 1 < a_wide; a++) {
+                    uint32_t nw[2 * NK + 1], nsh;
+                    load_row(a + 1, true, nw, nsh);
+                    accum(a, dw, sh);
+#pragma unroll
+                    for (int k = 0; k <= 2 * NK; k++) dw[k] = nw[k];
+                    sh = nsh;
+                }
+                accum(a, dw, sh);
+                a++;
+            }
+            for (; a < d.ry; a++) {
+                uint32_t dw[2 * NK + 1], sh;
+                load_row(a, (y0 + a) < ch_rows - 1, dw, sh);
+                accum(a, dw, sh);
             }
             uvt[cr][lane & 31] = (f2){ __builtin_truncf(acc.x / div), __builtin_truncf(acc.y / div) };
         }

@@ -92,3 +92,36 @@ def test_streaming_kernel_forced_everywhere_and_off(oracle, env, monkeypatch):
             run(v, oracle, y, uv, src[0], dst, planes=1)
     finally:
         v.Close()
+
+
+@pytest.mark.parametrize("src,dst,kernel", [
+    ((1920, 1080), (300, 300), "vpp_area_cols_kernel<2,"),    # 6.4 x 3.6: NK = 2
+    ((1920, 1080), (416, 416), "vpp_area_cols_kernel<2,"),    # 4.6 x 2.6
+    ((1920, 1080), (600, 400), "vpp_area_direct_float_kernel<1"),  # 3.2 x 2.7: up to four horizontal taps stay on the direct kernel (its neighbour in the dispatch)
+    ((3840, 2160), (416, 720), "vpp_area_cols_kernel<3,"),    # 9.2 x 3: NK = 3 (below the streaming kernel's cross-over: 30 taps)
+    ((1920, 1080), (270, 270), "vpp_area_cols_kernel<2,"),    # 7.1 x 4: 4 k + 2 columns
+])
+def test_column_per_lane_kernel_with_prefetch(vpp, oracle, src, dst, kernel):
+    """Round 6: vpp_area_cols_kernel requests tap row a + 1 before it accumulates tap row a (unconditional loads above the plane's last row, the edge loads only on it):
+    every instance, full frames (the bottom rows' last tap rows), crops -- and with the streaming kernel's divisor table switched off by a second context."""
+    import tensor_stream as ts
+    if not knob_run():
+        p = ts.describe(ts.FrameParameters(width=dst[0], height=dst[1], resize_type=AREA, normalization=True, planes_pos=0), src[0], src[1])
+        assert p["kernel"].startswith(kernel), p
+    y, uv = synth_nv12(src[0], src[1], seed=src[0] + 3 * dst[0])
+    run(vpp, oracle, y, uv, src[0], dst, planes=0, norm=True)
+    run(vpp, oracle, y, uv, src[0], dst, planes=1, norm=False)
+    run(vpp, oracle, y, uv, src[0], dst, fourcc=0, planes=1, norm=True)   # Y800: no chroma pass
+    w, h = src
+    run(vpp, oracle, y, uv, w, dst, crop=(w // 8 + 1, h // 8 + 1, w - w // 8 + 1, h - h // 8 + 1), norm=True)   # odd origin, other ratios' tables
+    old = os.environ.get("TSVPP_AREA_DIVTAB")
+    os.environ["TSVPP_AREA_DIVTAB"] = "0"   # (tests/conftest.py sets the debug gate): the kernel sums its weights itself
+    try:
+        v2 = ts.VideoProcessor(device=0)
+        run(v2, oracle, y, uv, src[0], dst, planes=0, norm=True)
+        v2.Close()
+    finally:
+        if old is None:
+            del os.environ["TSVPP_AREA_DIVTAB"]
+        else:
+            os.environ["TSVPP_AREA_DIVTAB"] = old
