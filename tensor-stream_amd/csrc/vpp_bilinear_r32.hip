@@ -218,8 +218,13 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
 #pragma unroll
             for (int r = 0; r < NCR; r++) {
                 const uint8_t *a = pc + (r_this + r) * (size_t)d.pitch_uv, *b = pc + (r_next + r) * (size_t)d.pitch_uv;
-                ce[r][0] = row_start ? 0u : *(const uint32_t *)(a - 4);
-                cn[r][0] = row_start ? 0u : *(const uint32_t *)(b - 4);
+                // (round 6) the dwords before / after the run are loaded UNCONDITIONALLY -- from the run's own first dword in the threads at a row's start / end, whose
+                // neighbours do not exist -- and zeroed by a select: written as `row_start ? 0 : load` these 36 loads sat in exec-masked branches and the compiler waited
+                // for each before it issued the next (`s_waitcnt vmcnt(0)` in front of 33 of the kernel's 94 loads)
+                const int before = row_start ? 0 : -4, after = row_end ? 0 : RUN;
+                const uint32_t eb = *(const uint32_t *)(a + before), nb = *(const uint32_t *)(b + before);
+                ce[r][0] = row_start ? 0u : eb;
+                cn[r][0] = row_start ? 0u : nb;
 #pragma unroll
                 for (int k = 0; k < P2; k++) {
                     ce[r][1 + k] = cs[r][k];
@@ -227,8 +232,9 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
                 }
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    ce[r][1 + P2 + k] = row_end ? 0u : *(const uint32_t *)(a + RUN + 4 * k);
-                    cn[r][1 + P2 + k] = row_end ? 0u : *(const uint32_t *)(b + RUN + 4 * k);
+                    const uint32_t ea = *(const uint32_t *)(a + after + (row_end ? 0 : 4 * k)), na = *(const uint32_t *)(b + after + (row_end ? 0 : 4 * k));
+                    ce[r][1 + P2 + k] = row_end ? 0u : ea;
+                    cn[r][1 + P2 + k] = row_end ? 0u : na;
                 }
             }
         }

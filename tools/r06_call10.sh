@@ -1,0 +1,7 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}; export TSVPP_DEBUG_KNOBS=1
+O=gpurun_out/r06; mkdir -p $O
+row() { printf "%-24s %-20s %-9s %-7s %-7s norm=%s " "$1" $2 $3 $4 $5 $6
+  env $1 python bench.py --custom $2:$3:$4:$5:$6 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); rf=r[\"roofline\"]; print(\"%9.0f fps %8.1f us frac %.3f %s %s\" % (r[\"value\"], rf[\"avg_launch_ms\"]*1e3, rf.get(\"roi_frac\", rf[\"frac\"]), rf[\"kernel\"][7:], r[\"config\"][\"parity\"][:9]))"; }
+{ row X=1 1920x1080:1280x720 BILINEAR YUV444 MERGED 0; row X=1 3840x2160:1920x1080 BILINEAR YUV444 MERGED 0; row X=1 1920x1080:1280x720 BILINEAR UYVY MERGED 0; } > $O/yuv444_u8.txt 2>&1; cat $O/yuv444_u8.txt
+QUICK=1 bash tools/r06_evidence.sh 1
