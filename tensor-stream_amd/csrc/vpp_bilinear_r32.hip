@@ -113,24 +113,41 @@ __device__ __forceinline__ float r32_vfilt(float cm1, float c, float cp1, float 
 // weights -- the pair's two taps are four consecutive bytes U V U V of a source row: two aligned dwords, v_alignbyte, one v_dot4 per component and
 // source row -- and the 4:2:2 chroma of a chroma row there.  Rows outside the image read as 0 (the reference's flat indexing runs off its buffer
 // there, src/ColorConversion.cu:131-138).  The plane base and the pitch are multiples of 4 (a condition of this kernel).
-template <int KIND, int P2> __device__ __forceinline__ void r32_pair_uv(const uint8_t *uv, int pitch, int cr, int cp, float &u, float &v) {
+// In two halves (round 6): r32_pair_taps requests the pair's dwords -- no branch, every address valid (cr clamped into the plane; the second dword of a row is asked for
+// only where the pair straddles it) -- and r32_pair_eval turns them into (U, V); a caller puts the taps of ALL its pairs in flight before it evaluates the first.
+// Written as one function per pair behind `if (cr in range)` / `if (cr odd)` the up to 96 loads of a row-end thread went out one round trip at a time.
+struct R32PairTaps {
+    uint32_t t0, t1, b0, b1;
+};
+template <int P2> __device__ __forceinline__ const uint8_t *r32_pair_ptr(const uint8_t *uv, int pitch, int cr, int cp) {
     const int fr = P2 == 4 ? 2 * cr : 3 * (cr >> 1) + (cr & 1), fc = P2 == 4 ? 2 * cp : 3 * (cp >> 1) + (cp & 1);
+    return uv + (size_t)fr * (size_t)pitch + (size_t)(2 * fc);
+}
+template <int KIND, int P2> __device__ __forceinline__ R32PairTaps r32_pair_taps(const uint8_t *uv, int pitch, int cr, int cp) {
+    const uint8_t *p = r32_pair_ptr<P2>(uv, pitch, cr, cp);
+    const uint32_t sh = (uint32_t)(uintptr_t)p & 3u; // 0 or 2
+    const uint32_t *a = (const uint32_t *)(p - sh);
+    const int second = sh ? 1 : 0;
+    R32PairTaps t;
+    t.t0 = a[0];
+    t.t1 = a[second];
+    t.b0 = t.b1 = 0u;
+    if (KIND != R32_NEAREST) {
+        const uint32_t *b = (const uint32_t *)(p - sh + pitch);
+        t.b0 = b[0];
+        t.b1 = b[second];
+    }
+    return t;
+}
+template <int KIND, int P2> __device__ __forceinline__ void r32_pair_eval(const R32PairTaps &t, const uint8_t *uv, int pitch, int cr, int cp, float &u, float &v) {
     const bool orow = (cr & 1) != 0, ocol = (cp & 1) != 0;
     constexpr uint32_t xe = (uint32_t)r32_wfirst<KIND, P2>(false) | ((uint32_t)r32_wsecond<KIND, P2>(false) << 16);
     constexpr uint32_t xo = (uint32_t)r32_wfirst<KIND, P2>(true) | ((uint32_t)r32_wsecond<KIND, P2>(true) << 16);
     const uint32_t wx = ocol ? xo : xe; // byte weights of U0 . U1 . (V: one byte up)
     const uint32_t wy0 = (uint32_t)(orow ? r32_wfirst<KIND, P2>(true) : r32_wfirst<KIND, P2>(false));
     const uint32_t wy1 = (uint32_t)(orow ? r32_wsecond<KIND, P2>(true) : r32_wsecond<KIND, P2>(false));
-    const uint8_t *p = uv + (size_t)fr * (size_t)pitch + (size_t)(2 * fc);
-    const uint32_t sh = (uint32_t)(uintptr_t)p & 3u; // 0 or 2
-    const uint32_t *a = (const uint32_t *)(p - sh);
-    uint32_t top = a[0], bot = 0;
-    if (sh) top = __builtin_amdgcn_alignbyte(a[1], top, sh);
-    if (KIND != R32_NEAREST) {
-        const uint32_t *b = (const uint32_t *)(p - sh + pitch);
-        bot = b[0];
-        if (sh) bot = __builtin_amdgcn_alignbyte(b[1], bot, sh);
-    }
+    const uint32_t sh = (uint32_t)(uintptr_t)r32_pair_ptr<P2>(uv, pitch, cr, cp) & 3u;
+    const uint32_t top = __builtin_amdgcn_alignbyte(t.t1, t.t0, sh), bot = __builtin_amdgcn_alignbyte(t.b1, t.b0, sh); // (shift 0: the first dword)
     uint32_t au = __builtin_amdgcn_udot4(top, wx * wy0, 0u, false), av = __builtin_amdgcn_udot4(top, (wx * wy0) << 8, 0u, false);
     if (KIND != R32_NEAREST) {
         au = __builtin_amdgcn_udot4(bot, wx * wy1, au, false);
@@ -147,19 +164,14 @@ template <int KIND, int P2> __device__ __forceinline__ void r32_pair_uv(const ui
         v = (float)(av & 255u);
     }
 }
-// 4:2:2 chroma of CHROMA row cr (= luma rows 2 cr, 2 cr + 1) at pair cp; `rows` = chroma rows of the image; cr outside it: 0
-template <int KIND, int P2> __device__ __forceinline__ void r32_uyvy_uv(const uint8_t *uv, int pitch, int rows, int cr, int cp, float &u, float &v) {
-    u = v = 0.0f;
-    if (cr < 0 || cr >= rows) return;
-    r32_pair_uv<KIND, P2>(uv, pitch, cr, cp, u, v);
-    if (!(cr & 1)) return;
-    const int last = rows - 1;
-    float um, vm, u1, v1, u2, v2;
-    r32_pair_uv<KIND, P2>(uv, pitch, cr - 1, cp, um, vm);
-    r32_pair_uv<KIND, P2>(uv, pitch, min(cr + 1, last), cp, u1, v1);
-    r32_pair_uv<KIND, P2>(uv, pitch, min(cr + 2, last), cp, u2, v2);
-    u = r32_vfilt(um, u, u1, u2);
-    v = r32_vfilt(vm, v, v1, v2);
+// The resized (U, V) of pair cp in the N consecutive chroma rows first .. first + N - 1, each clamped into the image: all taps first, then the arithmetic.
+template <int KIND, int P2, int N>
+__device__ __forceinline__ void r32_pair_column(const uint8_t *uv, int pitch, int rows, int first, int cp, float (&u)[N], float (&v)[N]) {
+    R32PairTaps t[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) t[k] = r32_pair_taps<KIND, P2>(uv, pitch, min(max(first + k, 0), rows - 1), cp);
+#pragma unroll
+    for (int k = 0; k < N; k++) r32_pair_eval<KIND, P2>(t[k], uv, pitch, min(max(first + k, 0), rows - 1), cp, u[k], v[k]);
 }
 template <int P2> __device__ __forceinline__ void r32_load(const uint8_t *p, uint32_t (&dw)[P2]) {
     if constexpr (P2 == 3) {
@@ -242,15 +254,32 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         // i0 + r - 1 (chroma rows 2 n4 - 1, 2 n4, 2 n4, 2 n4 + 1) and pairs 4, 5 from row i0 + r + 1 (chroma rows 2 n4, 2 n4 + 1, 2 n4 + 1, 2 n4 + 2)
         const int crows = d.dst_h >> 1, cpairs = d.dst_w >> 1, cr0 = 2 * n4;
         float ws[3][2] = {}, we[3][4] = {};
-        if (row_start) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 - 1 + k, cpairs - 1, ws[k][0], ws[k][1]);
+        // 4:2:2 chroma of chroma row cr = the resized pair when cr is even, the vertical filter over the resized pairs of rows cr - 1, cr, min(cr + 1, last),
+        // min(cr + 2, last) when it is odd, 0 outside the image.  cr0 is even and crows is even (dst_h % 4 == 0), so of the rows this tile needs only cr0 - 1 (above the
+        // first tile) and cr0 + 2 (below the last) can fall outside.
+        if (row_start) { // rows cr0 - 1 .. cr0 + 1 of the row's LAST pair: resized rows cr0 - 2 .. cr0 + 3
+            float pu[6], pv[6];
+            r32_pair_column<KIND, P2, 6>(t.uv[id.frame], d.pitch_uv, crows, cr0 - 2, cpairs - 1, pu, pv);
+            const bool above = cr0 > 0;
+            ws[0][0] = above ? r32_vfilt(pu[0], pu[1], pu[2], pu[3]) : 0.0f;
+            ws[0][1] = above ? r32_vfilt(pv[0], pv[1], pv[2], pv[3]) : 0.0f;
+            ws[1][0] = pu[2];
+            ws[1][1] = pv[2];
+            ws[2][0] = r32_vfilt(pu[2], pu[3], pu[4], pu[5]);
+            ws[2][1] = r32_vfilt(pv[2], pv[3], pv[4], pv[5]);
         }
-        if (row_end) {
+        if (row_end) { // rows cr0 .. cr0 + 2 of the row's FIRST two pairs: resized rows cr0 .. cr0 + 3
+            const bool under = cr0 + 2 < crows;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 + k, 0, we[k][0], we[k][1]);
-                r32_uyvy_uv<KIND, P2>(t.uv[id.frame], d.pitch_uv, crows, cr0 + k, 1, we[k][2], we[k][3]);
+            for (int cp = 0; cp < 2; cp++) {
+                float pu[4], pv[4];
+                r32_pair_column<KIND, P2, 4>(t.uv[id.frame], d.pitch_uv, crows, cr0, cp, pu, pv);
+                we[0][2 * cp] = pu[0];
+                we[0][2 * cp + 1] = pv[0];
+                we[1][2 * cp] = r32_vfilt(pu[0], pu[1], pu[2], pu[3]);
+                we[1][2 * cp + 1] = r32_vfilt(pv[0], pv[1], pv[2], pv[3]);
+                we[2][2 * cp] = under ? pu[2] : 0.0f;
+                we[2][2 * cp + 1] = under ? pv[2] : 0.0f;
             }
         }
         float c0[14], c1[14], c2[14], c3[14], cf[14];

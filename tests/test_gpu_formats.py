@@ -127,6 +127,48 @@ def test_row_pair_kernels(vpp, oracle, fcc, norm, src, pitch, dst, rt):
     assert bad.size == 0, (bad[:10], bad.size, ow, oh)
 
 
+@pytest.mark.parametrize("fcc", [UYVY, YUV444])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("src,pitch,dst,rt", [((1080, 608), 1088, (0, 0), 0),       # width 8 k, not 16 k: the 8-pixel uint8 instances
+                                              ((600, 338), 608, (0, 0), 0),         # the same, several partial waves
+                                              ((300, 200), 304, (0, 0), 0),         # width 4 k: the 4-pixel instances
+                                              ((1100, 64), 1104, (0, 0), 0),
+                                              ((12, 4), 16, (0, 0), 0),             # three / one thread per row
+                                              ((1366, 768), 1376, (0, 0), 0),       # width 4 k + 2: UYVY one pair per thread, YUV444 four pixels and a half thread at the row's end
+                                              ((854, 480), 854, (0, 0), 0),         # ... on a pitch that is no multiple of 4 either
+                                              ((10, 4), 10, (0, 0), 0),             # ... three threads per row, the last one half
+                                              ((14, 6), 16, (0, 0), 0),
+                                              ((258, 4), 258, (0, 0), 0),           # ... the half thread is lane 0 of a second workgroup
+                                              ((1026, 6), 1040, (0, 0), 0),
+                                              ((6, 4), 6, (0, 0), 0),               # widths below 8: neighbours that wrap more than one row
+                                              ((2, 2), 2, (0, 0), 0),
+                                              ((1920, 1080), 1920, (1080, 608), 1),   # behind a resize
+                                              ((1920, 1080), 1920, (1366, 768), 1),
+                                              ((1920, 1080), 1920, (300, 300), 3)])
+def test_row_pair_kernels_narrow_instances_and_one_pair_kernels(vpp, oracle, fcc, norm, src, pitch, dst, rt):
+    """Round 6: uint8 row-pair instances of 8 / 4 pixels per thread (YUV444) and 4 (UYVY) for widths that are no multiple of 16 / 8, the row ends' wrapped neighbours
+    loaded in one round trip, no alignment condition on planes / pitches / outputs (vector accesses at any address), YUV444 at widths 4 k + 2 (fmt_yuv444_rp_tail),
+    and what is left for the one-row kernels (frames narrower than two threads)."""
+    y, uv = synth_nv12(src[0], src[1], seed=fcc * 17 + src[0] + rt, pitch=pitch)
+    got = run(vpp, y, uv, fcc, norm, (0, 0, 0, 0), dst, rt, width=src[0]).ravel()
+    ref, ow, oh = oracle.convert(y, uv, dst=dst, resize_type=rt, fourcc=fcc, normalization=norm, nthreads=8, width=src[0])
+    assert got.dtype == ref.dtype and got.size == ref.size
+    bad = np.flatnonzero(got.view(np.uint8) != ref.view(np.uint8))
+    assert bad.size == 0, (bad[:10], bad.size, ow, oh)
+
+
+def test_one_pair_kernels_on_misaligned_outputs_and_crops(vpp, oracle):
+    """Crops whose origin misaligns the planes (byte loads), every format kernel family."""
+    y, uv = synth_nv12(1366, 768, seed=91, pitch=1371)
+    for fcc in (UYVY, YUV444):
+        for norm in (False, True):
+            for crop in ((0, 0, 0, 0), (2, 2, 1364, 766), (102, 50, 1182, 658), (100, 50, 400, 250)):   # widths 1362 (4 k + 2), 1080 (8 k), 300 (4 k)
+                got = run(vpp, y, uv, fcc, norm, crop, (0, 0), 0, width=1366).ravel()
+                ref, ow, oh = oracle.convert(y, uv, crop=crop, resize_type=0, fourcc=fcc, normalization=norm, nthreads=8, width=1366)
+                bad = np.flatnonzero(got.view(np.uint8) != ref.view(np.uint8))
+                assert got.size == ref.size and bad.size == 0, (fcc, norm, crop, bad[:10], bad.size)
+
+
 @pytest.mark.parametrize("chunk", range(3))
 def test_row_pair_kernels_fuzz(vpp, oracle, chunk):
     """Seeded fuzzing of UYVY / YUV444 at geometries the row-pair kernels take (widths that are multiples of 16, 16-byte pitches):
