@@ -194,6 +194,36 @@ def test_row_pair_kernels_fuzz(vpp, oracle, chunk):
         assert bad.size == 0, ((w, h, pitch, fcc, norm, dst, rt), bad[:8], bad.size)
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_formats_fuzz_any_even_width_pitch_and_crop(vpp, oracle, chunk):
+    """Round 6: UYVY / YUV444 at ANY even width and height, any pitch, odd crop origins (misaligned plane pointers), with and without a resize in front: every
+    width class (16 k, 8 k, 4 k, 4 k + 2, below two threads), the row-pair kernels' partial waves, the half thread of fmt_yuv444_rp_tail in every lane position."""
+    rng = np.random.default_rng(9100 + chunk)
+    for k in range(40):
+        w = 2 * int(rng.integers(1, 700))
+        h = 2 * int(rng.integers(1, 40))
+        pitch = w + int(rng.integers(0, 20))
+        fcc = int(rng.choice([UYVY, YUV444]))
+        norm = bool(rng.integers(0, 2))
+        crop = (0, 0, 0, 0)
+        if rng.random() < 0.4 and w >= 8 and h >= 8:
+            l, t = int(rng.integers(0, w // 4)), int(rng.integers(0, h // 4))
+            cw, ch = 2 * int(rng.integers(1, (w - l) // 2 + 1)), 2 * int(rng.integers(1, (h - t) // 2 + 1))
+            crop = (l, t, l + cw, t + ch)
+        dst, rt = (0, 0), 0
+        if rng.random() < 0.3:
+            dst, rt = (2 * int(rng.integers(1, 400)), 2 * int(rng.integers(1, 40))), int(rng.integers(0, 4))
+        y, uv = synth_nv12(w, h, seed=9000 + 100 * chunk + k, pitch=pitch)
+        try:
+            ref, ow, oh = oracle.convert(y, uv, crop=crop, dst=dst, resize_type=rt, fourcc=fcc, normalization=norm, nthreads=4, width=w)
+        except RuntimeError:
+            continue
+        got = run(vpp, y, uv, fcc, norm, crop, dst, rt, width=w).ravel()
+        assert got.dtype == ref.dtype and got.size == ref.size, (w, h, pitch, fcc, norm, crop, dst, rt)
+        bad = np.flatnonzero(got.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, ((w, h, pitch, fcc, norm, crop, dst, rt), bad[:8], bad.size)
+
+
 @pytest.mark.parametrize("fcc", [Y800, NV12])
 def test_plane_copies_16_bytes_per_lane(vpp, oracle, fcc):
     """No resize, uint8 Y800 / NV12: the output is the (cropped) planes made tight -- vpp_copy16_kernel where widths are multiples of 16 and heights of 4,
