@@ -1000,10 +1000,11 @@ int tsvpp_enable_markers(tsvpp_ctx *ctx, int on) {
     return TSVPP_OK;
 }
 
-// UYVY / YUV444 (uint8) behind a resize: does the streaming kernel take it (exact 3 : 2 or 2 : 1, BILINEAR / AREA / NEAREST, dword-aligned planes,
+static OutKind single_pass_kind(const Plan &pl) { return pl.fourcc == TSVPP_UYVY ? (pl.f32 ? O_UYVY_F32 : O_UYVY_U8) : O_YUV444_U8; }
+// UYVY / YUV444 (uint8; UYVY also fp32) behind a resize: does the streaming kernel take it (exact 3 : 2 or 2 : 1, BILINEAR / AREA / NEAREST, dword-aligned planes,
 // width % 8 == 0, height % 4 == 0, 16-byte aligned outputs)?  Asked of launch_fused itself, as a dry run: one set of conditions.
 static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void *const *outs, hipStream_t stream) {
-    if ((pl.fourcc != TSVPP_UYVY && pl.fourcc != TSVPP_YUV444) || pl.f32 || pl.mode == M_NONE) return false;
+    if ((pl.fourcc != TSVPP_UYVY && pl.fourcc != TSVPP_YUV444) || (pl.f32 && pl.fourcc != TSVPP_UYVY) || pl.mode == M_NONE) return false; // (fp32: UYVY only, round 6)
     if (outs)
         for (int f = 0; f < n; f++)
             if (((uintptr_t)outs[f] & 15) != 0) return false;
@@ -1011,7 +1012,7 @@ static bool single_pass_format(const Plan &pl, const LaunchDesc &d, int n, void 
     dd.n_frames = n < TSVPP_MAX_BATCH ? (n > 0 ? n : 1) : TSVPP_MAX_BATCH;
     FrameTable t = {};
     LaunchInfo info = {};
-    return launch_fused(pl.mode, pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8, true, dd, t, stream, &info) == hipSuccess;
+    return launch_fused(pl.mode, single_pass_kind(pl), true, dd, t, stream, &info) == hipSuccess;
 }
 
 // Device-resident columns of a tsvpp_table, already advanced to the run's first entry (null: the pointer triples travel in the kernarg segment).
@@ -1115,7 +1116,7 @@ static int convert_impl(tsvpp_ctx *ctx, int n, const tsvpp_nv12 *in, const tsvpp
         if (sts != TSVPP_OK) return sts;
         scratch = slot->buf;
     }
-    const OutKind out_kind = single ? (pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8) : pl.out;
+    const OutKind out_kind = single ? single_pass_kind(pl) : pl.out;
     if (two_pass && d.nt_stores < 0) d.nt_stores = 0; // the intermediate is read back at once: keep it in L2 / MALL
     // Frames per launch: TSVPP_MAX_BATCH with the pointer triples in the kernarg segment; out of a device-resident table (single-pass requests) up to
     // TSVPP_MAX_TABLE_LAUNCH, less where the grid would outgrow 2^31 threads (the smallest tile any kernel uses is 64 x 4 output pixels per workgroup of 256).
@@ -1485,10 +1486,10 @@ int tsvpp_describe(const tsvpp_params *p, int in_width, int in_height, int pitch
         }
     }
     const bool single = aligned_outputs != 0 && single_pass_format(pl, d, n_frames, nullptr, nullptr);
-    const OutKind out_kind = single ? (pl.fourcc == TSVPP_UYVY ? O_UYVY_U8 : O_YUV444_U8) : pl.out;
+    const OutKind out_kind = single ? single_pass_kind(pl) : pl.out;
     const bool two_pass = (pl.fourcc == TSVPP_UYVY || pl.fourcc == TSVPP_YUV444) && !single;
     d.n_frames = n_frames < TSVPP_MAX_BATCH ? n_frames : TSVPP_MAX_BATCH;
-    static const char *const out_names[O_COUNT_ALL] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32", "uyvy_u8", "yuv444_u8" };
+    static const char *const out_names[O_COUNT_ALL] = { "u8_planar", "u8_merged", "f32_planar", "f32_merged", "nv12_u8", "nv12_f32", "y800_u8", "y800_f32", "hsv_f32", "uyvy_u8", "yuv444_u8", "uyvy_f32" };
     static const char *const mode_names[M_COUNT] = { "none", "nearest", "bilinear", "bicubic", "area_down", "area_up" };
     LaunchInfo info = {};
     info.kernel = "(none)";

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
         }
         return;
     }
-    if constexpr (OUT == O_UYVY_U8) {
+    if constexpr (OUT == O_UYVY_U8 || OUT == O_UYVY_F32) {
         // UYVY (4:2:2) of the resized frame in the same pass (reference src/ColorConversion.cu:107-127, 177-209 on the resized NV12): luma rows
         // 2 r, 2 r + 1 take chroma row r as it is when r is even and clamp((9 (c[r] + c[r+1]) - (c[r-1] + c[r+2]) + 8) >> 4) when r is odd (rows
         // clamped to the last).  The tile's chroma rows are r = 2 n4 (even) and 2 n4 + 1 (odd): the odd one needs the two chroma rows of the tile
@@ -378,9 +378,30 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_r32_kernel(const Lau
             const r32x4 v = { pack_u8x4(c[0], yf[0], c[1], yf[1]), pack_u8x4(c[2], yf[2], c[3], yf[3]), pack_u8x4(c[4], yf[4], c[5], yf[5]),
                               pack_u8x4(c[6], yf[6], c[7], yf[7]) };
             const uint32_t pix = (uint32_t)(i0 + r) * (uint32_t)d.dst_w + (uint32_t)j0;
-            // 16 bytes per lane, 1 KiB contiguous per wave
-            if (nt) st16_nt(out, 2u * pix, (nt_u32x4){ v.x, v.y, v.z, v.w }, nt); // (inline asm: see st8_nt, vpp_device.h)
-            else *(r32x4 *)(out + 2u * (size_t)pix) = v;
+            if constexpr (OUT == O_UYVY_U8) {
+                // 16 bytes per lane, 1 KiB contiguous per wave
+                if (nt) st16_nt(out, 2u * pix, (nt_u32x4){ v.x, v.y, v.z, v.w }, nt); // (inline asm: see st8_nt, vpp_device.h)
+                else *(r32x4 *)(out + 2u * (size_t)pix) = v;
+            } else {
+                // fp32 (round 6: was a second pass over the uint8 NV12 of this kernel): the lane's 16 values would leave as four 16-byte stores 64 bytes apart -- a quarter of
+                // every line per instruction.  The lanes of a run (the lanes of the wave that share the output rows, A of them) trade their packed dwords through LDS instead:
+                // the run's 4 A dwords = groups of four values, lane m converts groups m, A + m, 2 A + m, 3 A + m, and every store instruction writes 16 A contiguous bytes.
+                __shared__ __attribute__((aligned(16))) uint8_t uslab[MAX_THREADS * 16];
+                const int len = min(d.tx, 64), run_m = (int)threadIdx.x & (len - 1);
+                const int run_a = min(len, (d.dst_w - (j0 - R32_COLS * run_m)) / R32_COLS);
+                uint8_t *run_lds = uslab + ((int)threadIdx.x - run_m) * 16;
+                *(r32x4 *)(run_lds + 16 * run_m) = v;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t row0 = 2u * (pix - (uint32_t)(R32_COLS * run_m)); // the run's first float of this row
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t g = (uint32_t)(k * run_a + run_m);
+                    const uint32_t w = *(const uint32_t *)(run_lds + 4u * g);
+                    const f2 a = norm255((f2){ (float)(w & 255u), (float)((w >> 8) & 255u) }), b = norm255((f2){ (float)((w >> 16) & 255u), (float)(w >> 24) });
+                    st4o(out, (row0 + 4u * g) * 4u, a.x, a.y, b.x, b.y, nt);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         return;
     }
@@ -490,7 +511,7 @@ template <int KIND, int P2>
 static hipError_t launch_r32_k(OutKind out, const LaunchDesc &d, const FrameTable &t, dim3 grid, dim3 block, hipStream_t stream) {
     switch (out) {
 #define TSVPP_R32(O) case O: TSVPP_LAUNCH((vpp_bilinear_r32_kernel<O, KIND, P2>), grid, block, 0, stream, d, t); break;
-        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8) TSVPP_R32(O_YUV444_U8)
+        TSVPP_R32(O_U8_PLANAR) TSVPP_R32(O_U8_MERGED) TSVPP_R32(O_NV12_U8) TSVPP_R32(O_Y800_U8) TSVPP_R32(O_UYVY_U8) TSVPP_R32(O_YUV444_U8) TSVPP_R32(O_UYVY_F32)
         TSVPP_R32(O_F32_PLANAR) TSVPP_R32(O_F32_MERGED) TSVPP_R32(O_NV12_F32) TSVPP_R32(O_Y800_F32) TSVPP_R32(O_HSV_F32)
 #undef TSVPP_R32
     default: return hipErrorInvalidValue;
@@ -507,7 +528,7 @@ hipError_t launch_bilinear_r32(OutKind out, const LaunchDesc &d, const FrameTabl
         if (d.r32 < 1 || d.r32 > 6) return hipErrorInvalidValue;
         info->kernel = names[d.r32 - 1];
         info->grid = (int)grid.x;
-        info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : (out == O_F32_MERGED || out == O_HSV_F32) ? MAX_THREADS * 96 : 16;
+        info->lds_bytes = out == O_U8_MERGED ? MAX_THREADS * 24 : (out == O_F32_MERGED || out == O_HSV_F32) ? MAX_THREADS * 96 : out == O_UYVY_F32 ? MAX_THREADS * 16 : 16;
         return hipSuccess;
     }
     switch (d.r32) {

@@ -382,35 +382,49 @@ typedef fvu4_a fvu4 __attribute__((aligned(1)));
 typedef fvu2_a fvu2 __attribute__((aligned(1)));
 typedef uint32_t fvu1 __attribute__((aligned(1)));
 
-template <class T, int PX>
+// Every load of the thread is requested before the first use (round 6: the luma loads used to follow the chroma filter, a second round trip -- the fp32 instance alone at
+// 1080p 0.63 -> 0.74 of the roofline, uint8 0.72 -> 0.735).  RPW row pairs per thread: 2 gains at 720p (0.74 -> 0.82) and loses at 1080p / 4K (0.742 -> 0.717, 0.747 -> 0.713,
+// profiles/r06_formats_ab.txt), so only RPW = 1 is instantiated.
+template <class T, int PX, int RPW>
 __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_uyvy_rp(const FrameTable t, const FmtGeom g) {
-    const int f = blockIdx.z, r = blockIdx.y * FMT_BY + threadIdx.y, j = (blockIdx.x * FMT_BX + threadIdx.x) * PX;
-    if (2 * r >= g.h || j >= g.w) return;
+    const int f = blockIdx.z, r0 = (blockIdx.y * FMT_BY + threadIdx.y) * RPW, j = (blockIdx.x * FMT_BX + threadIdx.x) * PX;
+    if (2 * r0 >= g.h || j >= g.w) return;
     const Nv12View s{ t.y[f], t.uv[f], g.py, g.puv, g.w, g.h };
     constexpr int ND = (PX + 3) / 4;
-    uint32_t c[ND], yy[2][ND];
-    chroma_rows<PX>(s, r, j, c);
-    ld_bytes<PX>(s.y + (size_t)(2 * r) * s.py + j, yy[0]);
-    ld_bytes<PX>(s.y + (size_t)(2 * r + 1) * s.py + j, yy[1]);
+    const int last_pair = (g.h >> 1) - 1;
+    uint32_t c[RPW][ND], yy[RPW][2][ND];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        T *o = (T *)t.out[f] + ((size_t)(2 * r + rr) * s.w + j) * 2;
-        if constexpr (sizeof(T) == 1 && PX == 8) { // (U Y V Y) x 4 = 16 bytes; v_perm_b32 interleaves chroma (S1) and luma (S0) bytes
-            fvu4_a v;
-            v.x = __builtin_amdgcn_perm(yy[rr][0], c[0], 0x05010400u);
-            v.y = __builtin_amdgcn_perm(yy[rr][0], c[0], 0x07030602u);
-            v.z = __builtin_amdgcn_perm(yy[rr][1], c[1], 0x05010400u);
-            v.w = __builtin_amdgcn_perm(yy[rr][1], c[1], 0x07030602u);
-            __builtin_nontemporal_store(v, (fvu4 *)o);
-        } else if constexpr (sizeof(T) == 1 && PX == 4) { // (round 6: widths 4 k that are no multiple of 8 -- 300, 1100, 1364): 8 bytes per lane
-            const fvu2_a v = { __builtin_amdgcn_perm(yy[rr][0], c[0], 0x05010400u), __builtin_amdgcn_perm(yy[rr][0], c[0], 0x07030602u) };
-            __builtin_nontemporal_store(v, (fvu2 *)o);
-        } else if constexpr (sizeof(T) == 1) { // PX = 2 (widths 4 k + 2: 1366, 854): one pair, 4 bytes per lane
-            __builtin_nontemporal_store(__builtin_amdgcn_perm(yy[rr][0], c[0], 0x05010400u), (fvu1 *)o);
-        } else { // PX = 2: U Y V Y as four floats
-            const fvf4_a v = { fin<float>((int)byte_of(c[0], 0)), fin<float>((int)byte_of(yy[rr][0], 0)), fin<float>((int)byte_of(c[0], 1)),
-                             fin<float>((int)byte_of(yy[rr][0], 1)) };
-            __builtin_nontemporal_store(v, (fvf4 *)o);
+    for (int k = 0; k < RPW; k++) {
+        const int r = min(r0 + k, last_pair); // (a row pair past the frame's last: loaded again, not stored)
+        ld_bytes<PX>(s.y + (size_t)(2 * r) * s.py + j, yy[k][0]);
+        ld_bytes<PX>(s.y + (size_t)(2 * r + 1) * s.py + j, yy[k][1]);
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; k++) chroma_rows<PX>(s, min(r0 + k, last_pair), j, c[k]);
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = r0 + k;
+        if (r > last_pair) break;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            T *o = (T *)t.out[f] + ((size_t)(2 * r + rr) * s.w + j) * 2;
+            if constexpr (sizeof(T) == 1 && PX == 8) { // (U Y V Y) x 4 = 16 bytes; v_perm_b32 interleaves chroma (S1) and luma (S0) bytes
+                fvu4_a v;
+                v.x = __builtin_amdgcn_perm(yy[k][rr][0], c[k][0], 0x05010400u);
+                v.y = __builtin_amdgcn_perm(yy[k][rr][0], c[k][0], 0x07030602u);
+                v.z = __builtin_amdgcn_perm(yy[k][rr][1], c[k][1], 0x05010400u);
+                v.w = __builtin_amdgcn_perm(yy[k][rr][1], c[k][1], 0x07030602u);
+                __builtin_nontemporal_store(v, (fvu4 *)o);
+            } else if constexpr (sizeof(T) == 1 && PX == 4) { // (round 6: widths 4 k that are no multiple of 8 -- 300, 1100, 1364): 8 bytes per lane
+                const fvu2_a v = { __builtin_amdgcn_perm(yy[k][rr][0], c[k][0], 0x05010400u), __builtin_amdgcn_perm(yy[k][rr][0], c[k][0], 0x07030602u) };
+                __builtin_nontemporal_store(v, (fvu2 *)o);
+            } else if constexpr (sizeof(T) == 1) { // PX = 2 (widths 4 k + 2: 1366, 854): one pair, 4 bytes per lane
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(yy[k][rr][0], c[k][0], 0x05010400u), (fvu1 *)o);
+            } else { // PX = 2: U Y V Y as four floats
+                const fvf4_a v = { fin<float>((int)byte_of(c[k][0], 0)), fin<float>((int)byte_of(yy[k][rr][0], 0)), fin<float>((int)byte_of(c[k][0], 1)),
+                                   fin<float>((int)byte_of(yy[k][rr][0], 1)) };
+                __builtin_nontemporal_store(v, (fvf4 *)o);
+            }
         }
     }
 }
@@ -621,10 +635,10 @@ hipError_t launch_format(int fourcc, bool f32, const FrameTable &t, int n, int p
         const dim3 block(FMT_BX, FMT_BY), grid((w / px + FMT_BX - 1) / FMT_BX, (h / 2 + FMT_BY - 1) / FMT_BY, n);
         const FmtGeom g{ py, puv, w, h, 1, 1 };
         if (fourcc == TSVPP_UYVY) {
-            if (f32) hipLaunchKernelGGL((fmt_uyvy_rp<float, 2>), grid, block, 0, stream, t, g);
-            else if (px == 8) hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 8>), grid, block, 0, stream, t, g);
-            else if (px == 4) hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 4>), grid, block, 0, stream, t, g);
-            else hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 2>), grid, block, 0, stream, t, g);
+            if (f32) hipLaunchKernelGGL((fmt_uyvy_rp<float, 2, 1>), grid, block, 0, stream, t, g);
+            else if (px == 8) hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 8, 1>), grid, block, 0, stream, t, g);
+            else if (px == 4) hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 4, 1>), grid, block, 0, stream, t, g);
+            else hipLaunchKernelGGL((fmt_uyvy_rp<uint8_t, 2, 1>), grid, block, 0, stream, t, g);
         } else {
             if (f32) hipLaunchKernelGGL((fmt_yuv444_rp<float, 4>), grid, block, 0, stream, t, g);
             else if (px == 16) hipLaunchKernelGGL((fmt_yuv444_rp<uint8_t, 16>), grid, block, 0, stream, t, g);

@@ -270,7 +270,7 @@ void geo_cache_destroy(GeoCache *c); // hipFree()s the tables: the caller has se
 enum OutKind : int { O_U8_PLANAR = 0, O_U8_MERGED, O_F32_PLANAR, O_F32_MERGED, O_NV12_U8, O_NV12_F32, O_Y800_U8, O_Y800_F32, O_HSV_F32, O_COUNT,
                      // flavours of the streaming 3 : 2 / 2 : 1 kernel only (vpp_bilinear_r32.hip): UYVY / YUV444 (uint8) behind such a resize in ONE pass -- everywhere else UYVY /
                      // YUV444 are a second pass over O_NV12_U8 (vpp_formats.hip).  launch_fused answers hipErrorNotSupported when the request is not that kernel's.
-                     O_UYVY_U8 = O_COUNT, O_YUV444_U8, O_COUNT_ALL };
+                     O_UYVY_U8 = O_COUNT, O_YUV444_U8, O_UYVY_F32 /* round 6: the same, every value / 255 as a float */, O_COUNT_ALL };
 
 // What launch_fused chose (dry run, see tsvpp_describe).
 struct LaunchInfo {

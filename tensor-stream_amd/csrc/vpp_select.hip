@@ -68,7 +68,8 @@ static int stream_select(Mode mode, OutKind out, bool vec, const LaunchDesc &d, 
                    ((2 * d.src_w == d.dst_w && 2 * d.src_h == d.dst_h) ? 1 : 0));
     if (!p2) return 0;
     const bool f32_out = (out == O_F32_PLANAR || out == O_F32_MERGED || out == O_NV12_F32 || out == O_Y800_F32 || out == O_HSV_F32);
-    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8);
+    const bool u8_flavour = (out == O_U8_PLANAR || out == O_U8_MERGED || out == O_NV12_U8 || out == O_Y800_U8 || out == O_UYVY_U8 || out == O_YUV444_U8 ||
+                             out == O_UYVY_F32); // (fp32, but a flavour of this kernel alone: nothing else to lose against)
     int r32 = 0;
     for (const StreamRow &row : kStreamRows)
         if (row.mode == mode && row.p2 == p2) r32 = row.r32;

@@ -97,14 +97,21 @@ def test_r32_uyvy_yuv444_in_one_pass(vpp, oracle, src, pitch, rt, ratio, fmt):
         assert dsc["out"] == ("uyvy_u8" if fmt == UYVY else "yuv444_u8") and dsc["kernel"].startswith("vpp_bilinear_r32_kernel") and "pass2" not in dsc, dsc
     check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt)
     check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt, n=5)
+    if fmt == UYVY:   # round 6: fp32 UYVY too (the lanes of a run trade their packed dwords through LDS: whole-line float stores; partial runs, one-thread rows)
+        fpn = ts.FrameParameters(width=dst[0], height=dst[1], resize_type=rt, pixel_format=fmt, planes_pos=1, normalization=True)
+        if not knob_run():
+            dsc = V.describe(fpn, w, h, pitch=pitch)
+            assert dsc["out"] == "uyvy_f32" and dsc["kernel"].startswith("vpp_bilinear_r32_kernel") and "pass2" not in dsc, dsc
+        check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt, norm=True)
+        check(vpp, oracle, y, uv, w, dst, fourcc=fmt, planes=1, rt=rt, norm=True, n=3)
 
 
 def test_r32_uyvy_fallbacks(vpp, oracle):
-    """Requests next to the single-pass domain keep the two passes: fp32 UYVY / YUV444, a misaligned crop origin, a misaligned output."""
+    """Requests next to the single-pass domain keep the two passes: fp32 YUV444, BICUBIC, a misaligned crop origin, a misaligned output."""
     import tensor_stream as ts
     from tensor_stream import vpp as V
     y, uv = synth_nv12(1920, 1080, seed=35, pitch=2048)
-    for kw in (dict(pixel_format=UYVY, normalization=True), dict(pixel_format=YUV444, normalization=True), dict(pixel_format=UYVY, normalization=False, crop_coords=(6, 2, 966, 542), width=640, height=360)):
+    for kw in (dict(pixel_format=UYVY, normalization=True, resize_type=2), dict(pixel_format=YUV444, normalization=True), dict(pixel_format=UYVY, normalization=False, crop_coords=(6, 2, 966, 542), width=640, height=360)):
         args = dict(width=1280, height=720, resize_type=BILINEAR, planes_pos=1)
         args.update(kw)
         dsc = V.describe(ts.FrameParameters(**args), 1920, 1080, pitch=2048)

@@ -156,12 +156,12 @@ def test_output_flavours_share_the_sampling_kernels():
         # (HSV at exactly 3 : 2 / 2 : 1: the streaming kernel -- three divisions per pixel make that flavour VALU-bound, round 4)
         assert p["out"] == out and p["kernel"].startswith("vpp_bilinear_r32_kernel<" if fourcc == HSV else "vpp_bilinear_kernel<")
     assert plan((1920, 1080), (1280, 720), B, fourcc=Y800, norm=False)["out"] == "y800_u8"
-    p = plan((1920, 1080), (1280, 720), B, fourcc=UYVY)
+    p = plan((1920, 1080), (1366, 768), B, fourcc=UYVY)
     assert p["out"] == "nv12_u8" and p["pass2"] == "fmt_uyvy"            # two passes: resized NV12, then the format kernel
     p = plan((1920, 1080), (0, 0), N, fourcc=YUV444)
     assert p["kernel"] == "(none)" and p["pass2"] == "fmt_yuv444"        # no resize: the format kernel reads the input itself
-    # uint8 UYVY / YUV444 behind an exact 3 : 2 / 2 : 1 resize: ONE pass, an output of the streaming kernel (round 3) -- for its three tap kinds, not for
-    # fp32, BICUBIC, other ratios, misaligned crops or misaligned outputs
+    # uint8 UYVY / YUV444 (round 3) and fp32 UYVY (round 6) behind an exact 3 : 2 / 2 : 1 resize: ONE pass, an output of the streaming kernel -- for its three
+    # tap kinds, not for fp32 YUV444, BICUBIC, other ratios, misaligned crops or misaligned outputs
     for rt, kind in ((B, "bilinear"), (A, "area"), (N, "nearest")):
         p = plan((1920, 1080), (1280, 720), rt, fourcc=UYVY, norm=False)
         assert p["out"] == "uyvy_u8" and p["kernel"] == "vpp_bilinear_r32_kernel<OUT,%s,3:2>" % kind and "pass2" not in p
@@ -169,7 +169,10 @@ def test_output_flavours_share_the_sampling_kernels():
         assert p["out"] == "uyvy_u8" and p["kernel"] == "vpp_bilinear_r32_kernel<OUT,%s,2:1>" % kind and "pass2" not in p
         p = plan((1920, 1080), (1280, 720), rt, fourcc=YUV444, norm=False)
         assert p["out"] == "yuv444_u8" and p["kernel"] == "vpp_bilinear_r32_kernel<OUT,%s,3:2>" % kind and "pass2" not in p
-    for kw in (dict(fourcc=YUV444, norm=True), dict(fourcc=UYVY, norm=True), dict(fourcc=UYVY, norm=False, rt=C), dict(fourcc=UYVY, norm=False, dst=(1000, 720)),
+        for src, dst, ratio in (((1920, 1080), (1280, 720), "3:2"), ((3840, 2160), (1920, 1080), "2:1")):
+            p = plan(src, dst, rt, fourcc=UYVY, norm=True)
+            assert p["out"] == "uyvy_f32" and p["kernel"] == "vpp_bilinear_r32_kernel<OUT,%s,%s>" % (kind, ratio) and "pass2" not in p
+    for kw in (dict(fourcc=YUV444, norm=True), dict(fourcc=UYVY, norm=True, rt=C), dict(fourcc=UYVY, norm=True, dst=(1000, 720)), dict(fourcc=UYVY, norm=False, rt=C), dict(fourcc=UYVY, norm=False, dst=(1000, 720)),
                dict(fourcc=UYVY, norm=False, dst=(640, 360), crop=(6, 2, 966, 542)), dict(fourcc=UYVY, norm=False, aligned_outputs=False)):
         args = dict(src=(1920, 1080), dst=(1280, 720), rt=B)
         args.update(kw)
