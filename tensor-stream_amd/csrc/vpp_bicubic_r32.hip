@@ -30,13 +30,13 @@ namespace tsvpp {
 // load (fp32 planar 1080p -> 720p 0.64 -> 0.71, 4K -> 1080p 0.68 -> 0.73: profiles/r04_bicubic_r32_ab.txt).  Only the first / last lane of a wave
 // -- their neighbour is in another wave -- load theirs: two single-lane loads per row.  For workgroups 64 threads wide (a wave = one run of lanes
 // that share their output rows); narrower workgroups (uint8 outputs of widths that would idle lanes: VALU-bound, not TA-bound) keep the three loads.
+// (round 6) The two flavours are chosen ONCE around both planes' loads in the kernel, and the neighbour dwords are zeroed before any load is issued: with `if (!wide)` inside a
+// per-plane function the chroma call came behind the merge of the luma call's two branches, where the compiler has to assume the other branch's loads in flight to the same
+// registers -- it put `s_waitcnt vmcnt(8)` in front of the last lane's loads, i.e. made every wave wait for its main loads before it requested its last neighbour dwords (a
+// second memory round trip per tile).
 template <int P2, int NROWS>
-__device__ __forceinline__ void bcr_load_rows(const uint8_t *plane, int pitch, int row0, int plane_rows, int q, bool first, bool last, bool wide, bool run_first,
-                                              bool run_last, uint32_t (&ext)[NROWS][P2 + 2], uint32_t (&nb)[NROWS][2]) {
-    if (!wide) {
-        bc_load_rows<P2, NROWS>(plane, pitch, row0, plane_rows, q, first, last, ext);
-        return;
-    }
+__device__ __forceinline__ void bcr_load_rows_wide(const uint8_t *plane, int pitch, int row0, int plane_rows, int q, bool first, bool last, bool run_first, bool run_last,
+                                                   uint32_t (&ext)[NROWS][P2 + 2], uint32_t (&nb)[NROWS][2]) {
     constexpr int RUN = 4 * P2;
     const uint32_t col = (uint32_t)(RUN * q);
     uint32_t off[NROWS];
@@ -44,8 +44,6 @@ __device__ __forceinline__ void bcr_load_rows(const uint8_t *plane, int pitch, i
     for (int r = 0; r < NROWS; r++) {
         off[r] = (uint32_t)bc_row<NROWS>(row0, r, plane_rows) * (uint32_t)pitch + col;
         bc_ld<P2>(plane + off[r], &ext[r][1]);
-        nb[r][0] = 0u; // (any defined value: the lanes that do not load below take their neighbour's dword)
-        nb[r][1] = 0u;
     }
     if (run_first && !first) {
 #pragma unroll
@@ -87,10 +85,16 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bicubic_r32_kernel(const Laun
     const int run_a = min(run_len, (d.dst_w - (j0 - BCR_COLS * run_m)) / BCR_COLS);
     const bool run_first = run_m == 0, run_last = run_m == run_a - 1;
     // every load of the tile first, then the neighbour shuffles and the column edge fix-ups, then the arithmetic
-    uint32_t ey[G::NYR][P2 + 2], xy[G::NYR][2], ec[G::NCR][P2 + 2], xc[G::NCR][2], ny[G::NYR][2], nc[G::NCR][2];
+    uint32_t ey[G::NYR][P2 + 2], xy[G::NYR][2], ec[G::NCR][P2 + 2], xc[G::NCR][2];
+    uint32_t ny[G::NYR][2] = {}, nc[G::NCR][2] = {}; // (any defined value: the lanes that do not load theirs take their neighbour's dword)
     const bool wide = d.tx >= 64; // wave-uniform: a wave is one run
-    bcr_load_rows<P2, G::NYR>(t.y[id.frame], d.pitch_y, 2 * P2 * n4 - 1, d.src_h, q, first, last, wide, run_first, run_last, ey, ny);
-    if constexpr (!LUMA_ONLY) bcr_load_rows<P2, G::NCR>(t.uv[id.frame], d.pitch_uv, P2 * n4 - 1, d.src_h >> 1, q, first, last, wide, run_first, run_last, ec, nc);
+    if (wide) {
+        bcr_load_rows_wide<P2, G::NYR>(t.y[id.frame], d.pitch_y, 2 * P2 * n4 - 1, d.src_h, q, first, last, run_first, run_last, ey, ny);
+        if constexpr (!LUMA_ONLY) bcr_load_rows_wide<P2, G::NCR>(t.uv[id.frame], d.pitch_uv, P2 * n4 - 1, d.src_h >> 1, q, first, last, run_first, run_last, ec, nc);
+    } else {
+        bc_load_rows<P2, G::NYR>(t.y[id.frame], d.pitch_y, 2 * P2 * n4 - 1, d.src_h, q, first, last, ey);
+        if constexpr (!LUMA_ONLY) bc_load_rows<P2, G::NCR>(t.uv[id.frame], d.pitch_uv, P2 * n4 - 1, d.src_h >> 1, q, first, last, ec);
+    }
 #ifndef TSVPP_BCR_NO_SCHED_BARRIER
     // nothing is scheduled across this point: without it the compiler sinks the loads into three batches between the arithmetic of the row groups
     // (fewer live registers, but a wave then waits for memory three times per tile)

@@ -21,21 +21,17 @@
 
 namespace tsvpp {
 
+// (round 6: the wide / narrow choice is made ONCE around both planes' loads in the kernel and the neighbour dwords are zeroed before any load is issued -- see
+// bcr_load_rows_wide, vpp_bicubic_r32.hip: behind the merge of a per-plane `if (!wide)` the compiler made every wave wait for its main loads before the last lane's.)
 template <int NROWS>
-__device__ __forceinline__ void u2k_load_rows(const uint8_t *plane, int pitch, int row0, int plane_rows, int q, bool first, bool last, bool wide, bool run_first,
-                                              bool run_last, uint32_t (&ext)[NROWS][3], uint32_t (&nb)[NROWS][2]) {
-    if (!wide) {
-        u2_load_rows<NROWS>(plane, pitch, row0, plane_rows, q, first, last, ext);
-        return;
-    }
+__device__ __forceinline__ void u2k_load_rows_wide(const uint8_t *plane, int pitch, int row0, int plane_rows, int q, bool first, bool last, bool run_first, bool run_last,
+                                                   uint32_t (&ext)[NROWS][3], uint32_t (&nb)[NROWS][2]) {
     const uint32_t col = 4u * (uint32_t)q;
     uint32_t off[NROWS];
 #pragma unroll
     for (int r = 0; r < NROWS; r++) {
         off[r] = (uint32_t)u2_row(row0, r, plane_rows) * (uint32_t)pitch + col;
         bc_ld<1>(plane + off[r], &ext[r][1]);
-        nb[r][0] = 0u; // (any defined value: the lanes that do not load below take their neighbour's dword)
-        nb[r][1] = 0u;
     }
     if (run_first && !first) {
 #pragma unroll
@@ -75,10 +71,16 @@ __global__ __launch_bounds__(MAX_THREADS) void vpp_bilinear_up2_kernel(const Lau
     const int run_a = min(run_len, (d.dst_w - (j0 - BCR_COLS * run_m)) / BCR_COLS);
     const bool run_first = run_m == 0, run_last = run_m == run_a - 1;
     // every load of the tile first, then the neighbour shuffles and the column edge fix-ups, then the arithmetic
-    uint32_t ey[U2_NYR][3], ec[U2_NCR][3], ny[U2_NYR][2], nc[U2_NCR][2];
+    uint32_t ey[U2_NYR][3], ec[U2_NCR][3];
+    uint32_t ny[U2_NYR][2] = {}, nc[U2_NCR][2] = {}; // (any defined value: the lanes that do not load theirs take their neighbour's dword)
     const bool wide = d.tx >= 64; // wave-uniform: a wave is one run
-    u2k_load_rows<U2_NYR>(t.y[id.frame], d.pitch_y, 2 * n4 - 1, d.src_h, q, first, last, wide, run_first, run_last, ey, ny);
-    if constexpr (!LUMA_ONLY) u2k_load_rows<U2_NCR>(t.uv[id.frame], d.pitch_uv, n4 - 1, d.src_h >> 1, q, first, last, wide, run_first, run_last, ec, nc);
+    if (wide) {
+        u2k_load_rows_wide<U2_NYR>(t.y[id.frame], d.pitch_y, 2 * n4 - 1, d.src_h, q, first, last, run_first, run_last, ey, ny);
+        if constexpr (!LUMA_ONLY) u2k_load_rows_wide<U2_NCR>(t.uv[id.frame], d.pitch_uv, n4 - 1, d.src_h >> 1, q, first, last, run_first, run_last, ec, nc);
+    } else {
+        u2_load_rows<U2_NYR>(t.y[id.frame], d.pitch_y, 2 * n4 - 1, d.src_h, q, first, last, ey);
+        if constexpr (!LUMA_ONLY) u2_load_rows<U2_NCR>(t.uv[id.frame], d.pitch_uv, n4 - 1, d.src_h >> 1, q, first, last, ec);
+    }
     __builtin_amdgcn_sched_barrier(0); // nothing is scheduled across this point: all loads of the tile are in flight together
     u2k_neighbours<U2_NYR>(ey, ny, wide);
     if constexpr (!LUMA_ONLY) u2k_neighbours<U2_NCR>(ec, nc, wide);

@@ -550,9 +550,23 @@ __global__ __launch_bounds__(FMT_BX *FMT_BY) void fmt_yuv444_rp_tail(const Frame
         tr[1] = chroma_taps_any(s, r + 1, 0);
     }
     uint32_t cl, co, cr;
-    chroma_rows<4>(s, r, jl, &cl);
-    chroma_rows<4>(s, r, jo, &co);
-    chroma_rows<4>(s, r, jr, &cr);
+    { // chroma_rows<4> at the three columns, the loads of all three before the first filter (one round trip on odd chroma rows too)
+        const int last = (s.h >> 1) - 1, cols[3] = { jl, jo, jr };
+        uint32_t a[3], b[3], c[3], e[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) a[k] = ld4<false>(s.uv + (size_t)r * s.puv + cols[k]);
+        if (r & 1) { // uniform per wave
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                b[k] = ld4<false>(s.uv + (size_t)min(r + 1, last) * s.puv + cols[k]);
+                c[k] = ld4<false>(s.uv + (size_t)max(r - 1, 0) * s.puv + cols[k]);
+                e[k] = ld4<false>(s.uv + (size_t)min(r + 2, last) * s.puv + cols[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) a[k] = vfilt4(a[k], b[k], c[k], e[k]);
+        }
+        cl = a[0]; co = a[1]; cr = a[2];
+    }
     uint32_t wl[2] = { cl, cl }, wr[2] = { 0u, 0u };
     if (row_first) {
         wl[0] = chroma_taps_filter(s, r - 1, tl[0]);
