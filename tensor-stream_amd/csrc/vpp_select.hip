@@ -207,6 +207,15 @@ static void sel_shapes(Mode mode, OutKind out, LaunchDesc &d, FusedSel &S) {
         shapes[1][0] = shapes[0][0]; shapes[1][1] = shapes[0][1];
         shapes[0][0] = 64; shapes[0][1] = 4;
     }
+    // The colour-only kernel (no resize) with planar fp32 outputs writes the same three-plane pattern (round 6, profiles/r06_color_shapes.txt): at output widths that are
+    // multiples of 256 its 32 x 8 workgroups (128 x 16 pixels) reach 0.62-0.64 of the roofline at 1280 / 2560 / 3840 columns against 0.73-0.74 at 1920 -- and 0.72-0.74 on
+    // 64 x 4 (256 x 8 pixels: 1 KiB row segments per plane); 2048 columns 0.73 -> 0.76.  1024 and 640 columns do not care (-1.5 % / 0), uint8 planar loses at 1280 (-6 %).
+    if (mode == M_NONE && out == O_F32_PLANAR && d.dst_w % 256 == 0 && d.dst_w >= 1280) {
+        shapes[3][0] = shapes[2][0]; shapes[3][1] = shapes[2][1];
+        shapes[2][0] = shapes[1][0]; shapes[2][1] = shapes[1][1];
+        shapes[1][0] = shapes[0][0]; shapes[1][1] = shapes[0][1];
+        shapes[0][0] = 64; shapes[0][1] = 4;
+    }
     // uint8 outputs on the integer window tile read host-built geometry tables (vpp_bilinear.hip): with workgroups 64 thread tiles
     // wide a wave's lanes share their output rows and the row records are scalar loads -- measured (profiles/r02_geo_ab.txt)
     // 1080p -> 720p planar 0.545 -> 0.570, merged 0.481 -> 0.506, 4K -> 1080p 0.706 -> 0.717 against 32 x 8

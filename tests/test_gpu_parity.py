@@ -141,6 +141,13 @@ def test_config_C2_1080p_bgr_planar_fp32(vpp, oracle):
     check(vpp, oracle, y, uv, fourcc=BGR24, planes=PLANAR, normalization=True)
 
 
+def test_colour_only_planar_fp32_on_256x8_tiles(vpp, oracle):
+    """Round 6: the colour-only kernel on 64 x 4 workgroups (widths that are multiples of 256, from 1280 columns): every pixel of 720p and 1440p frames, a padded pitch."""
+    for (w, h, pitch) in ((1280, 720, 1280), (2560, 1440, 2816)):
+        y, uv = synth_nv12(w, h, seed=w, pitch=pitch)
+        check(vpp, oracle, y, uv, width=w, fourcc=BGR24, planes=PLANAR, normalization=True)
+
+
 def test_config_C3_crop_bilinear_256(vpp, oracle):
     y, uv = synth_nv12(1920, 1080, seed=3)
     check(vpp, oracle, y, uv, crop=(0, 0, 1280, 720), dst=(256, 256), resize_type=BILINEAR, fourcc=RGB24, planes=PLANAR, normalization=True)

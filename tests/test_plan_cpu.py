@@ -150,6 +150,17 @@ def test_small_outputs_keep_two_row_thread_tiles():
     assert plan((1920, 1080), (1280, 720), B, norm=False, pitch=1922)["lds"] <= 20 * 1024
 
 
+def test_colour_only_planar_fp32_takes_256x8_tiles_at_widths_that_fill_them():
+    """Round 6 (profiles/r06_color_shapes.txt): no resize, planar fp32, 1280 / 2560 / 3840 columns: 0.62-0.64 of the roofline on 32 x 8 workgroups, 0.72-0.74 on 64 x 4."""
+    for src in ((1280, 720), (2560, 1440), (3840, 2160), (2048, 1152)):
+        p = plan(src, (0, 0), N)
+        assert p["kernel"] == "vpp_color_kernel<OUT>" and p["shape"] == "64x4", (src, p)
+    assert plan((1920, 1080), (0, 0), N)["shape"] == "32x8"              # C2: 7.5 tiles of 256 columns
+    assert plan((1024, 576), (0, 0), N)["shape"] == "32x8"               # no gain below 1280 columns
+    assert plan((1280, 720), (0, 0), N, norm=False)["shape"] == "32x8"   # uint8 planar loses 6 % on the wide tiles
+    assert plan((1280, 720), (0, 0), N, planes=1)["shape"] == "32x8"     # merged: the exchange pattern, not this one
+
+
 def test_output_flavours_share_the_sampling_kernels():
     for fourcc, out in [(Y800, "y800_f32"), (NV12, "nv12_f32"), (HSV, "hsv_f32"), (RGB24, "f32_planar")]:
         p = plan((1920, 1080), (1280, 720), B, fourcc=fourcc)
