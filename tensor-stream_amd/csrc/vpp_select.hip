@@ -184,6 +184,12 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
         d.nt_stores = f32_partial ? 0 : ((mode == M_NONE && f32_lines) ? 2 : 1);
         // bit 2: the 4-byte uint8 stores non-temporal too -- only the colour-only kernel's planar output gains (st1o, vpp_device.h)
         if (mode == M_NONE && out == O_U8_PLANAR && vec) d.nt_stores = 1 | 4;
+        // Planar fp32 rows that are no multiple of 64 bytes (round 6, profiles/r06_row_alignment.txt): a wave's 1 KiB row segment then starts and ends inside a line it shares
+        // with the neighbouring workgroup's segment, and non-temporal stores send both halves of that line to memory on their own -- three planes at once.  Output width
+        // 1360 (rows of 85 x 64 bytes) 0.71, 1376 (43 x 128) 0.74-0.75, but 1362 / 1364 / 1366 / 1370 0.58-0.60 and 1368 (171 x 32) 0.65.  Plain stores let L2 put the lines
+        // together: 1366 columns BILINEAR 0.58 -> 0.68, AREA 0.46 -> 0.60, BICUBIC 0.43 -> 0.50, colour-only 0.43 -> 0.52, 854 columns 0.585 -> 0.67, 1368 +4...7 %.  They
+        // LOSE 3-8 % on rows of whole lines, on one- / two-plane outputs (Y800, NV12) and on merged ones, and do nothing for small frames (300 / 600 columns): those stay.
+        if (out == O_F32_PLANAR && vec && ((size_t)d.dst_w * 4) % 64 != 0 && d.dst_w >= 800) d.nt_stores = 0;
     }
 }
 
