@@ -633,7 +633,11 @@ hipError_t launch_fused(Mode mode, OutKind out, bool vec, const LaunchDesc &din,
     const float ratio_area = d.xr * d.yr;
     const int bc_r32 = (stream_r32 == 7 || stream_r32 == 8) ? stream_r32 : 0;
     // (BICUBIC: only the integer kernel for dyadic weights stages; everything else is vpp_bicubic_cols.hip)
-    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 30.0f && !bc_r32;
+    // (round 6, profiles/r06_bicubic_int_vs_cols.txt: the cross-over is a ratio product of ~6.5, not 30 -- the integer kernel stages and H-filters every source row of its
+    // footprint, the column kernel's EXACT instance walks the same dyadic weights without the tie test: 4K -> 960 x 540 (4 x 4) 385 / 472 us per 64 frames (planar fp32 /
+    // merged uint8) against 241 / 214, 4K -> 1024 x 576 287 / 342 against 219 / 222, 1080p -> 640 x 480 (3 x 2.25) 97 / 103 against 89 / 78; a tie at 2.5 x 2.5; below, and for
+    // every up-scale, the integer kernel wins by 2-40 %)
+    const bool bicubic_staged = mode == M_BICUBIC && d.w_dyadic && d.bicubic_int_pref && d.bicubic_cols_pref != 2 && ratio_area < 6.5f && !bc_r32;
     // (round 6: BILINEAR leaves the LDS-staged kernel for the row-segment kernel already from a ratio product of 7.5 when the vertical ratio is at least 2.1 -- the staged kernel
     // fetches every source row of its footprint, the row-segment kernel two per output row: 1080p -> 416^2 (4.6 x 2.6) 561 -> 373 us per 512 frames, -> 480^2 (4 x 2.25) 507 -> 469,
     // 4K -> 1024^2 (3.75 x 2.1) 285 -> 269; at a vertical ratio of 2.0 and below the staged kernel wins: 1080p -> 540^2 731 vs 756, -> 800^2 912 vs 1079; profiles/r06_point_rows_ab.txt)
