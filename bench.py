@@ -453,7 +453,7 @@ def parse_args(argv=None):
                     "independent batches of N consumers: one launch's drain overlaps the next one's fill; avg_launch_ms is then wall time per launch, not a launch's duration")
     ap.add_argument("--resize", default=None, choices=sorted(RESIZE), help="override the resize type")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets")
-    ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM, e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
+    ap.add_argument("--custom", default=None, help="ad-hoc workload SRCWxSRCH:DSTWxDSTH:RESIZE:FOURCC:PLANES:NORM[:L,T,R,B crop], e.g. 1920x1080:224x224:BILINEAR:RGB24:PLANAR:1")
     ap.add_argument("--per-call", type=int, default=0, help="frames per C-ABI call (default: the whole batch); 1 = the reference's one Convert per frame")
     ap.add_argument("--graph", action="store_true", help="capture a step's calls in a hipGraph and replay it (launch-bound small calls)")
     ap.add_argument("--tight-pitch", action="store_true", help="source pitch = width instead of width rounded up to 256 bytes")
@@ -479,7 +479,8 @@ def resolve_spec(args):
         a = args.custom.split(":")
         sw, sh = (int(x) for x in a[0].split("x"))
         dw, dh = (int(x) for x in a[1].split("x"))
-        spec = [sw, sh, (sw + 255) // 256 * 256, (0, 0, 0, 0), (dw, dh), a[2], a[3], a[4], a[5] == "1"]
+        crop = tuple(int(x) for x in a[6].split(",")) if len(a) > 6 else (0, 0, 0, 0)   # optional 7th field: the crop box left,top,right,bottom
+        spec = [sw, sh, (sw + 255) // 256 * 256, crop, (dw, dh), a[2], a[3], a[4], a[5] == "1"]
         name = "custom"
     if args.resize:
         spec[5] = args.resize

@@ -56,7 +56,8 @@ def test_cpu_baseline_leg(tight, rt, norm, planes):
 
 
 FLAG_SETS = [[], ["--tight-pitch"], ["--workload", "c4"], ["--workload", "c3", "--tight-pitch"], ["--resize", "AREA"],
-             ["--custom", "640x360:320x180:BICUBIC:RGB24:MERGED:0"], ["--per-call", "1"], ["--workload", "c5", "--no-others"]]
+             ["--custom", "640x360:320x180:BICUBIC:RGB24:MERGED:0"], ["--custom", "640x360:160x120:BILINEAR:RGB24:PLANAR:1:100,40,420,280"],   # (with a crop box)
+             ["--per-call", "1"], ["--workload", "c5", "--no-others"]]
 
 
 @pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: " ".join(f) or "default")
