@@ -182,6 +182,10 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
         const bool f32_lines = (out == O_F32_PLANAR || out == O_NV12_F32 || out == O_Y800_F32) || (vec && (out == O_F32_MERGED || out == O_HSV_F32));
         const bool f32_partial = !vec && (out == O_F32_MERGED || out == O_HSV_F32);
         d.nt_stores = f32_partial ? 0 : ((mode == M_NONE && f32_lines) ? 2 : 1);
+        // The colour-only kernel's variant 2 was chosen on C2 (1080p planar fp32: 0.71 against 0.66 on variant 1) -- and holds for three-plane / merged outputs 1920 and 2048
+        // columns wide only (round 6, profiles/r06_color_shapes.txt part 5): Y800 fp32 gains 6-22 % on variant 1 at every size (1080p 0.74 -> 0.79, 720p 0.70 -> 0.85, 4K 0.74 ->
+        // 0.81), NV12 fp32 2-22 % (2048 columns: -4 %), planar / merged below 1536 columns 1-15 % (640 x 360 0.65 -> 0.75, 720p merged 0.70 -> 0.76).
+        if (mode == M_NONE && f32_lines && d.nt_stores == 2 && (out == O_Y800_F32 || out == O_NV12_F32 || d.dst_w < 1536)) d.nt_stores = 1;
         // bit 2: the 4-byte uint8 stores non-temporal too -- only the colour-only kernel's planar output gains (st1o, vpp_device.h)
         if (mode == M_NONE && out == O_U8_PLANAR && vec) d.nt_stores = 1 | 4;
         // Planar fp32 rows that are no multiple of 64 bytes (round 6, profiles/r06_row_alignment.txt): a wave's 1 KiB row segment then starts and ends inside a line it shares
@@ -190,6 +194,11 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
         // together: 1366 columns BILINEAR 0.58 -> 0.68, AREA 0.46 -> 0.60, BICUBIC 0.43 -> 0.50, colour-only 0.43 -> 0.52, 854 columns 0.585 -> 0.67, 1368 +4...7 %.  They
         // LOSE 3-8 % on rows of whole lines, on one- / two-plane outputs (Y800, NV12) and on merged ones, and do nothing for small frames (300 / 600 columns): those stay.
         if (out == O_F32_PLANAR && vec && ((size_t)d.dst_w * 4) % 64 != 0 && d.dst_w >= 800) d.nt_stores = 0;
+        // ... and the colour-only kernel with EVERY fp32 flavour (profiles/r06_row_alignment.txt, part 6): 1366 x 768 merged 0.44 -> 0.55, HSV 0.43 -> 0.53, NV12 0.46 -> 0.57,
+        // Y800 0.45 -> 0.56 (behind a resize those flavours tie or lose with plain stores: the LDS kernels keep their non-temporal ones)
+        if (mode == M_NONE && vec && (out == O_F32_MERGED || out == O_HSV_F32 || out == O_NV12_F32 || out == O_Y800_F32) && d.dst_w >= 800 &&
+            ((size_t)d.dst_w * 4 * ((out == O_F32_MERGED || out == O_HSV_F32) ? 3 : 1)) % 64 != 0)
+            d.nt_stores = 0;
     }
 }
 
