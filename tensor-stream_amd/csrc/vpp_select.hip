@@ -187,7 +187,9 @@ static void sel_store_policy(Mode mode, OutKind out, bool vec, LaunchDesc &d) {
         // 0.81), NV12 fp32 2-22 % (2048 columns: -4 %), planar / merged below 1536 columns 1-15 % (640 x 360 0.65 -> 0.75, 720p merged 0.70 -> 0.76).
         if (mode == M_NONE && f32_lines && d.nt_stores == 2 && (out == O_Y800_F32 || out == O_NV12_F32 || d.dst_w < 1536)) d.nt_stores = 1;
         // bit 2: the 4-byte uint8 stores non-temporal too -- only the colour-only kernel's planar output gains (st1o, vpp_device.h)
-        if (mode == M_NONE && out == O_U8_PLANAR && vec) d.nt_stores = 1 | 4;
+        // (round 6, profiles/r06_color_shapes.txt part 7: ... where the output rows are multiples of 64 bytes -- 720p 0.73 -> 0.755, 1080p 0.73 -> 0.77, 960 x 540 0.58 -> 0.68;
+        // at 1360 / 1366 / 1918 / 854 columns the same bit LOSES 8-20 %: 1360 x 768 0.63 -> 0.51)
+        if (mode == M_NONE && out == O_U8_PLANAR && vec && d.dst_w % 64 == 0) d.nt_stores = 1 | 4;
         // Planar fp32 rows that are no multiple of 64 bytes (round 6, profiles/r06_row_alignment.txt): a wave's 1 KiB row segment then starts and ends inside a line it shares
         // with the neighbouring workgroup's segment, and non-temporal stores send both halves of that line to memory on their own -- three planes at once.  Output width
         // 1360 (rows of 85 x 64 bytes) 0.71, 1376 (43 x 128) 0.74-0.75, but 1362 / 1364 / 1366 / 1370 0.58-0.60 and 1368 (171 x 32) 0.65.  Plain stores let L2 put the lines
